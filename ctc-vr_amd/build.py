@@ -1,0 +1,43 @@
+"""Build librnnt_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch involved."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "rnnt_api.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "rnnt_kernels.hip.h"), os.path.join(os.path.dirname(HERE), "include", "rnnt_hip.h")]
+LIB = os.path.join(HERE, "librnnt_hip.so")
+
+
+def lib_path():
+    return LIB
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-o", LIB, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building librnnt_hip.so")
+    if verbose:
+        sys.stderr.write(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose="-v" in sys.argv)
+    print(LIB)

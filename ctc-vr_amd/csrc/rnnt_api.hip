@@ -1,0 +1,778 @@
+// librnnt_hip.so — host side: context, weight ingest/packing, per-chunk launch sequences, C ABI.
+// See include/rnnt_hip.h for the contract and DESIGN.md for the data layout in HBM.
+#include "rnnt_kernels.hip.h"
+#include "../../include/rnnt_hip.h"
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int D = RNNT_D, FF = RNNT_FF, L = RNNT_L, DK = RNNT_DK;
+constexpr int BIG = INT_MAX;
+
+struct LayerW {
+    const float *ln_ffm_g, *ln_ffm_b, *w1m, *b1m, *w2m, *b2m;
+    const float *ln_mha_g, *ln_mha_b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *pu, *pv;
+    float* ptab;   // [5000][256] = pe * W_pos^T
+    const float *wpos;
+    const float *ln_conv_g, *ln_conv_b, *pw1, *bpw1, *wdw_t, *bdw, *bn_s, *bn_t, *pw2, *bpw2;
+    const float *ln_ff_g, *ln_ff_b, *w1, *b1, *w2, *b2, *ln_fin_g, *ln_fin_b;
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> dims;
+};
+
+}  // namespace
+
+struct rnnt_ctx {
+    rnnt_config cfg;
+    std::string err;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    int numerics = 0;
+
+    // packed weights (one device blob)
+    float* blob = nullptr;
+    size_t blob_floats = 0;
+    LayerW lw[L];
+    const float *conv1_wt, *conv1_b, *conv2_w, *conv2_b, *emb_w, *emb_b, *pe, *after_g, *after_b;
+    const float *ln_conv_g_all, *ln_conv_b_all, *glu0;
+    const float *whh_il, *wih_il, *b_lstm_il, *pred_embed, *wpr, *bpr, *wenc, *benc, *wpf, *bpf, *wout, *bout;
+    float* egate = nullptr;   // [vocab][1024] interleaved input-gate table
+
+    // geometry
+    int tmax = 0, t1max = 0, cap = 0, tcap = 0, fcap = 0, fstride = 0, vpad = 0;
+    // activations
+    float *y1 = nullptr, *y2 = nullptr, *x = nullptr, *hbuf = nullptr, *qbuf = nullptr, *abuf = nullptr, *dbuf = nullptr;
+    float *kcache = nullptr, *vcache = nullptr, *gring = nullptr, *xring = nullptr;
+    float *encbuf = nullptr, *encp = nullptr;
+    // decode state
+    float *h = nullptr, *c = nullptr, *h2 = nullptr, *c2 = nullptr, *pred = nullptr, *z = nullptr, *logits = nullptr;
+    int *tok = nullptr, *fidx = nullptr, *nsym = nullptr, *count = nullptr, *tokens = nullptr, *n_active = nullptr, *klen = nullptr;
+    int* pinned = nullptr;   // host-pinned scratch (n_active read-back)
+    float* scratch = nullptr;  // device scratch for getters / step API
+    size_t scratch_floats = 0;
+
+    // stream state (all streams lock step)
+    int n_streams = 0;
+    int cache_len = 0, kv_start = 0, conv_pos = 0;
+    int frames_buffered = 0, frames_decoded = 0;
+    int64_t launches = 0, greedy_steps = 0;
+};
+
+namespace {
+
+int fail(rnnt_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, RNNT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCHCHK(name)                                                                                \
+    do {                                                                                               \
+        hipError_t e_ = hipGetLastError();                                                             \
+        if (e_ != hipSuccess) return fail(ctx, RNNT_ERR_HIP, "launch %s failed: %s", name, hipGetErrorString(e_)); \
+        ctx->launches++;                                                                               \
+    } while (0)
+
+template <typename T>
+int dmalloc(rnnt_ctx* ctx, T** p, size_t n) {
+    if (hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)) != hipSuccess)
+        return fail(ctx, RNNT_ERR_OOM, "hipMalloc of %zu bytes failed", n * sizeof(T));
+    return RNNT_OK;
+}
+
+inline int sub_len(int T) { return ((T - 3) / 2 + 1 - 3) / 2 + 1; }   // subsampling.py:188-193
+inline int sub1_len(int T) { return (T - 3) / 2 + 1; }
+
+GemmP plain_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                 int epi = EPI_BIAS, float alpha = 1.f) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.W = W; p.bias = bias; p.C = C; p.R = nullptr; p.ln_g = nullptr; p.ln_b = nullptr;
+    p.M = M; p.N = N; p.K = K;
+    p.a_n1 = BIG; p.a_n2 = BIG; p.a_s0 = 0; p.a_s1 = 0; p.a_s2 = lda; p.a_seg = BIG; p.a_seg_stride = 0;
+    p.ldw = ldw;
+    p.c_n = BIG; p.c_r0 = 0; p.c_mod = BIG; p.c_s0 = 0; p.c_s1 = ldc;
+    p.epi = epi; p.alpha = alpha;
+    p.x_n = 1;
+    return p;
+}
+
+int launch_gemm(rnnt_ctx* ctx, hipStream_t s, int wk, const GemmP* gs, int ng) {
+    GemmBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    int maxM = 0, maxN = 0;
+    for (int i = 0; i < ng; ++i) {
+        gb.g[i] = gs[i];
+        if (gs[i].K % (wk * 8) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm K=%d not divisible by %d", gs[i].K, wk * 8);
+        if (gs[i].ln_g && gs[i].K != 256) return fail(ctx, RNNT_ERR_SHAPE, "LayerNorm prologue needs K=256");
+        maxM = gs[i].M > maxM ? gs[i].M : maxM;
+        maxN = gs[i].N > maxN ? gs[i].N : maxN;
+    }
+    if (maxM <= 0 || maxN <= 0) return RNNT_OK;
+    dim3 grid((maxN + 31) / 32, (maxM + 31) / 32, ng);
+    size_t lds = (size_t)(wk * 1024 + 64) * sizeof(float);
+    switch (wk) {
+        case 1: hipLaunchKernelGGL(gemm32<1>, grid, dim3(64), lds, s, gb); break;
+        case 2: hipLaunchKernelGGL(gemm32<2>, grid, dim3(128), lds, s, gb); break;
+        case 4: hipLaunchKernelGGL(gemm32<4>, grid, dim3(256), lds, s, gb); break;
+        case 8: hipLaunchKernelGGL(gemm32<8>, grid, dim3(512), lds, s, gb); break;
+        case 16: hipLaunchKernelGGL(gemm32<16>, grid, dim3(1024), lds, s, gb); break;
+        default: return fail(ctx, RNNT_ERR_ARG, "bad WK %d", wk);
+    }
+    LAUNCHCHK("gemm32");
+    return RNNT_OK;
+}
+
+inline int grid_for(long long n, int block = 256) {
+    long long g = (n + block - 1) / block;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+const HostTensor* find(rnnt_ctx* ctx, const std::string& name) {
+    auto it = ctx->host.find(name);
+    return it == ctx->host.end() ? nullptr : &it->second;
+}
+
+// the attention / conv / FFN part of one Conformer block over rows [M = B*tq] of ctx->x
+// (ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:188-265).
+int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv_row0, int pos_start, int ring_pos,
+              const int* klen_dev) {
+    const LayerW& w = ctx->lw[l];
+    const int M = B * tq;
+    int rc;
+    // x += 0.5 * FFN_macaron(LN(x))
+    {
+        GemmP g1 = plain_gemm(ctx->x, D, w.w1m, D, w.b1m, ctx->hbuf, FF, M, FF, D, EPI_SILU);
+        g1.ln_g = w.ln_ffm_g; g1.ln_b = w.ln_ffm_b;
+        if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+        GemmP g2 = plain_gemm(ctx->hbuf, FF, w.w2m, FF, w.b2m, ctx->x, D, M, D, FF, EPI_RESID, 0.5f);
+        g2.R = ctx->x;
+        if ((rc = launch_gemm(ctx, s, 16, &g2, 1))) return rc;
+    }
+    // x += linear_out(attention(LN(x)))
+    {
+        float* kc = ctx->kcache + (size_t)l * ctx->cfg.max_streams * ctx->tcap * D;
+        float* vc = ctx->vcache + (size_t)l * ctx->cfg.max_streams * ctx->tcap * D;
+        GemmP g[3];
+        g[0] = plain_gemm(ctx->x, D, w.wq, D, w.bq, ctx->qbuf, D, M, D, D);
+        g[1] = plain_gemm(ctx->x, D, w.wk, D, w.bk, kc, D, M, D, D);
+        g[2] = plain_gemm(ctx->x, D, w.wv, D, w.bv, vc, D, M, D, D);
+        for (int i = 0; i < 3; ++i) { g[i].ln_g = w.ln_mha_g; g[i].ln_b = w.ln_mha_b; }
+        for (int i = 1; i < 3; ++i) {   // append the new K/V rows behind the cached ones
+            g[i].c_n = tq; g[i].c_s0 = (long long)ctx->tcap * D; g[i].c_r0 = kv_row0 + (T2 - tq); g[i].c_mod = BIG; g[i].c_s1 = D;
+        }
+        if ((rc = launch_gemm(ctx, s, 8, g, 3))) return rc;
+        dim3 grid(B * RNNT_H, (tq + ATT_QB - 1) / ATT_QB);
+        hipLaunchKernelGGL(rel_attention, grid, dim3(256), 0, s, ctx->qbuf, kc, vc, w.ptab, w.pu, w.pv, klen_dev, ctx->abuf, tq, T2,
+                           (long long)ctx->tcap, kv_row0, pos_start);
+        LAUNCHCHK("rel_attention");
+        GemmP go = plain_gemm(ctx->abuf, D, w.wo, D, w.bo, ctx->x, D, M, D, D, EPI_RESID, 1.0f);
+        go.R = ctx->x;
+        if ((rc = launch_gemm(ctx, s, 8, &go, 1))) return rc;
+    }
+    // x += conv_module(LN(x))
+    {
+        float* gr = ctx->gring + (size_t)l * ctx->cfg.max_streams * ctx->cap * D;
+        float* xr = ctx->xring + (size_t)l * ctx->cfg.max_streams * ctx->cap * D;
+        GemmP g1 = plain_gemm(ctx->x, D, w.pw1, D, w.bpw1, gr, D, M, 2 * D, D, EPI_GLU);
+        g1.ln_g = w.ln_conv_g; g1.ln_b = w.ln_conv_b;
+        g1.c_n = tq; g1.c_s0 = (long long)ctx->cap * D; g1.c_r0 = ring_pos % ctx->cap; g1.c_mod = ctx->cap; g1.c_s1 = D;
+        if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+        hipLaunchKernelGGL(dwconv_bn_silu, dim3(grid_for((long long)M * D)), dim3(256), 0, s, gr, w.wdw_t, w.bdw, w.bn_s, w.bn_t,
+                           ctx->dbuf, B, tq, ctx->cap, ring_pos, ctx->x, xr);
+        LAUNCHCHK("dwconv_bn_silu");
+        GemmP g2 = plain_gemm(ctx->dbuf, D, w.pw2, D, w.bpw2, ctx->x, D, M, D, D, EPI_RESID, 1.0f);
+        g2.R = ctx->x;
+        if ((rc = launch_gemm(ctx, s, 8, &g2, 1))) return rc;
+    }
+    // x += 0.5 * FFN(LN(x)); x = LN_final(x)
+    {
+        GemmP g1 = plain_gemm(ctx->x, D, w.w1, D, w.b1, ctx->hbuf, FF, M, FF, D, EPI_SILU);
+        g1.ln_g = w.ln_ff_g; g1.ln_b = w.ln_ff_b;
+        if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+        GemmP g2 = plain_gemm(ctx->hbuf, FF, w.w2, FF, w.b2, ctx->x, D, M, D, FF, EPI_RESID, 0.5f);
+        g2.R = ctx->x;
+        if ((rc = launch_gemm(ctx, s, 16, &g2, 1))) return rc;
+        hipLaunchKernelGGL(layer_norm, dim3((M + 3) / 4), dim3(256), 0, s, ctx->x, w.ln_fin_g, w.ln_fin_b, ctx->x, M, BIG, 0LL, 0,
+                           (long long)D);
+        LAUNCHCHK("layer_norm");
+    }
+    return RNNT_OK;
+}
+
+// Conv2dSubsampling4 (+ x16) of fbank [B,T,80] into ctx->x rows [B*t'] (subsampling.py:203-228).
+int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T) {
+    const int t1 = sub1_len(T), tq = sub_len(T);
+    int rc;
+    hipLaunchKernelGGL(conv1_relu, dim3(grid_for((long long)B * t1 * RNNT_F1 * D)), dim3(256), 0, s, fbank, ctx->conv1_wt, ctx->conv1_b,
+                       ctx->y1, B, T, t1);
+    LAUNCHCHK("conv1_relu");
+    // conv2 as implicit GEMM: rows (b,t',f), K = (kh, kw, ci) = 3 segments of 768 contiguous floats of y1
+    GemmP g = plain_gemm(ctx->y1, 0, ctx->conv2_w, 2304, ctx->conv2_b, ctx->y2, D, B * tq * RNNT_FSUB, D, 2304, EPI_RELU);
+    g.a_n1 = tq * RNNT_FSUB; g.a_n2 = RNNT_FSUB;
+    g.a_s0 = (long long)t1 * RNNT_F1 * D; g.a_s1 = 2LL * RNNT_F1 * D; g.a_s2 = 2LL * D;
+    g.a_seg = 768; g.a_seg_stride = (long long)RNNT_F1 * D;
+    if ((rc = launch_gemm(ctx, s, 8, &g, 1))) return rc;
+    // Linear(4864 -> 256) * sqrt(256); y2 is [B*t', f*256 + c] (weight columns permuted to match)
+    GemmP go = plain_gemm(ctx->y2, RNNT_FSUB * D, ctx->emb_w, RNNT_FSUB * D, ctx->emb_b, ctx->x, D, B * tq, D, RNNT_FSUB * D, EPI_SCALE, 16.0f);
+    if ((rc = launch_gemm(ctx, s, 16, &go, 1))) return rc;
+    return RNNT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnnt_abi_version(void) { return 1; }
+
+const char* rnnt_last_error(const rnnt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
+    if (!cfg || !out) return RNNT_ERR_ARG;
+    *out = nullptr;
+    rnnt_ctx* ctx = new rnnt_ctx();
+    ctx->cfg = *cfg;
+    *out = ctx;   // returned even on failure so the caller can read rnnt_last_error, then destroy
+    if (cfg->max_streams < 1 || cfg->max_chunk_frames < 7 || cfg->max_cache_frames < 1 || cfg->max_cache_frames > RNNT_PE_LEN ||
+        cfg->max_enc_frames < 1 || cfg->max_tokens < 1 || cfg->vocab_size < 2 || cfg->blank_id < 0 || cfg->blank_id >= cfg->vocab_size ||
+        cfg->n_steps < 1)
+        return fail(ctx, RNNT_ERR_ARG, "rnnt_create: bad config");
+    HIPCHK(hipSetDevice(cfg->device));
+    const int B = cfg->max_streams;
+    ctx->tmax = sub_len(cfg->max_chunk_frames);
+    ctx->t1max = sub1_len(cfg->max_chunk_frames);
+    ctx->cap = RNNT_LORDER + ctx->tmax;
+    ctx->tcap = cfg->max_cache_frames;
+    ctx->fcap = cfg->max_enc_frames;
+    ctx->fstride = ctx->fcap + 1;   // +1 row: finished streams read one frame past the end
+    ctx->vpad = (cfg->vocab_size + 31) / 32 * 32;
+    const size_t M = (size_t)B * ctx->tmax;
+    int rc;
+#define ALLOC(p, n) if ((rc = dmalloc(ctx, &ctx->p, (size_t)(n)))) return rc
+    ALLOC(y1, (size_t)B * ctx->t1max * RNNT_F1 * D);
+    ALLOC(y2, M * RNNT_FSUB * D);
+    ALLOC(x, M * D);
+    ALLOC(hbuf, M * FF);
+    ALLOC(qbuf, M * D);
+    ALLOC(abuf, M * D);
+    ALLOC(dbuf, M * D);
+    ALLOC(kcache, (size_t)L * B * ctx->tcap * D);
+    ALLOC(vcache, (size_t)L * B * ctx->tcap * D);
+    ALLOC(gring, (size_t)L * B * ctx->cap * D);
+    ALLOC(xring, (size_t)L * B * ctx->cap * D);
+    ALLOC(encbuf, (size_t)B * ctx->fstride * D);
+    ALLOC(encp, (size_t)B * ctx->fstride * D);
+    ALLOC(h, (size_t)B * D); ALLOC(c, (size_t)B * D); ALLOC(h2, (size_t)B * D); ALLOC(c2, (size_t)B * D);
+    ALLOC(pred, (size_t)B * D); ALLOC(z, (size_t)B * D); ALLOC(logits, (size_t)B * ctx->vpad);
+    ALLOC(tok, B); ALLOC(fidx, B); ALLOC(nsym, B); ALLOC(count, B); ALLOC(tokens, (size_t)B * cfg->max_tokens);
+    ALLOC(n_active, 4); ALLOC(klen, B);
+    ctx->scratch_floats = (size_t)L * RNNT_H * ctx->tcap * 128;
+    if (ctx->scratch_floats < (size_t)B * ctx->fstride * D) ctx->scratch_floats = (size_t)B * ctx->fstride * D;
+    ALLOC(scratch, ctx->scratch_floats);
+#undef ALLOC
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 64));
+    HIPCHK(hipMemset(ctx->encbuf, 0, (size_t)B * ctx->fstride * D * sizeof(float)));
+    HIPCHK(hipMemset(ctx->encp, 0, (size_t)B * ctx->fstride * D * sizeof(float)));
+    return RNNT_OK;
+}
+
+void rnnt_destroy(rnnt_ctx* ctx) {
+    if (!ctx) return;
+    void* ptrs[] = {ctx->blob, ctx->egate, ctx->y1, ctx->y2, ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf, ctx->kcache, ctx->vcache,
+                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->h2, ctx->c2, ctx->pred, ctx->z, ctx->logits,
+                    ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int l = 0; l < L; ++l)
+        if (ctx->lw[l].ptab) (void)hipFree(ctx->lw[l].ptab);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+}
+
+int rnnt_load_tensor(rnnt_ctx* ctx, const char* name, const float* host_data, int32_t ndim, const int64_t* dims) {
+    if (!ctx || !name || ndim < 0 || ndim > 8) return fail(ctx, RNNT_ERR_ARG, "rnnt_load_tensor: bad argument");
+    std::string n(name);
+    if (n.find("num_batches_tracked") != std::string::npos) return RNNT_OK;   // int64 counter, unused in eval
+    if (!host_data) return fail(ctx, RNNT_ERR_ARG, "rnnt_load_tensor(%s): null data", name);
+    HostTensor t;
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (dims[i] < 0) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_load_tensor(%s): negative dim", name);
+        t.dims.push_back(dims[i]);
+        cnt *= (size_t)dims[i];
+    }
+    t.data.assign(host_data, host_data + cnt);
+    ctx->host[n] = std::move(t);
+    ctx->finalized = false;
+    return RNNT_OK;
+}
+
+int rnnt_finalize_weights(rnnt_ctx* ctx, int32_t numerics_mode, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    if (numerics_mode != RNNT_NUMERICS_FP32) return fail(ctx, RNNT_ERR_ARG, "unsupported numerics mode %d", numerics_mode);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const int V = ctx->cfg.vocab_size;
+    std::vector<float> blob;
+    std::vector<std::pair<const float**, size_t>> fix;   // pointer slots to patch with blob offsets
+    auto need = [&](const std::string& name, std::initializer_list<int64_t> dims) -> const HostTensor* {
+        const HostTensor* t = find(ctx, name);
+        if (!t) { fail(ctx, RNNT_ERR_STATE, "missing tensor %s", name.c_str()); return nullptr; }
+        if (t->dims != std::vector<int64_t>(dims)) { fail(ctx, RNNT_ERR_SHAPE, "tensor %s has the wrong shape", name.c_str()); return nullptr; }
+        return t;
+    };
+    auto put = [&](const float** slot, const float* data, size_t n) {
+        while (blob.size() % 4) blob.push_back(0.f);   // 16-byte alignment of every tensor
+        fix.push_back({slot, blob.size()});
+        blob.insert(blob.end(), data, data + n);
+    };
+    auto putv = [&](const float** slot, const std::vector<float>& v) { put(slot, v.data(), v.size()); };
+#define NEED(var, name, ...) const HostTensor* var = need(name, {__VA_ARGS__}); if (!var) return ctx->err.find("missing") != std::string::npos ? RNNT_ERR_STATE : RNNT_ERR_SHAPE
+
+    // --- subsampling -------------------------------------------------------------------------
+    NEED(c1w, "encoder.embed.conv.0.weight", D, 1, 3, 3);
+    NEED(c1b, "encoder.embed.conv.0.bias", D);
+    NEED(c2w, "encoder.embed.conv.2.weight", D, D, 3, 3);
+    NEED(c2b, "encoder.embed.conv.2.bias", D);
+    NEED(eow, "encoder.embed.out.0.weight", D, D * RNNT_FSUB);
+    NEED(eob, "encoder.embed.out.0.bias", D);
+    NEED(pe, "encoder.embed.pos_enc.pe", 1, RNNT_PE_LEN, D);
+    NEED(ang, "encoder.after_norm.weight", D);
+    NEED(anb, "encoder.after_norm.bias", D);
+    {
+        std::vector<float> w1t(9 * D);   // [kh*3+kw][c]
+        for (int c = 0; c < D; ++c)
+            for (int k = 0; k < 9; ++k) w1t[k * D + c] = c1w->data[c * 9 + k];
+        putv(&ctx->conv1_wt, w1t);
+        put(&ctx->conv1_b, c1b->data.data(), D);
+        std::vector<float> w2((size_t)D * 2304);   // [co][kh][kw][ci]
+        for (int co = 0; co < D; ++co)
+            for (int ci = 0; ci < D; ++ci)
+                for (int k = 0; k < 9; ++k) w2[(size_t)co * 2304 + k * D + ci] = c2w->data[((size_t)co * D + ci) * 9 + k];
+        putv(&ctx->conv2_w, w2);
+        put(&ctx->conv2_b, c2b->data.data(), D);
+        std::vector<float> ew((size_t)D * RNNT_FSUB * D);   // column c*19+f -> f*256+c
+        for (int n = 0; n < D; ++n)
+            for (int c = 0; c < D; ++c)
+                for (int f = 0; f < RNNT_FSUB; ++f) ew[(size_t)n * RNNT_FSUB * D + f * D + c] = eow->data[(size_t)n * RNNT_FSUB * D + c * RNNT_FSUB + f];
+        putv(&ctx->emb_w, ew);
+        put(&ctx->emb_b, eob->data.data(), D);
+        put(&ctx->pe, pe->data.data(), (size_t)RNNT_PE_LEN * D);
+        put(&ctx->after_g, ang->data.data(), D);
+        put(&ctx->after_b, anb->data.data(), D);
+    }
+    // --- encoder layers ----------------------------------------------------------------------
+    std::vector<float> lncg((size_t)L * D), lncb((size_t)L * D), glu0((size_t)L * D);
+    for (int l = 0; l < L; ++l) {
+        LayerW& w = ctx->lw[l];
+        const std::string p = "encoder.encoders." + std::to_string(l) + ".";
+        auto vec = [&](const float** slot, const std::string& nm, std::initializer_list<int64_t> dims) -> int {
+            const HostTensor* t = need(p + nm, dims);
+            if (!t) return -1;
+            put(slot, t->data.data(), t->data.size());
+            return 0;
+        };
+#define VEC(slot, nm, ...) if (vec(&w.slot, nm, {__VA_ARGS__})) return RNNT_ERR_STATE
+        VEC(ln_ffm_g, "norm_ff_macaron.weight", D); VEC(ln_ffm_b, "norm_ff_macaron.bias", D);
+        VEC(w1m, "feed_forward_macaron.w_1.weight", FF, D); VEC(b1m, "feed_forward_macaron.w_1.bias", FF);
+        VEC(w2m, "feed_forward_macaron.w_2.weight", D, FF); VEC(b2m, "feed_forward_macaron.w_2.bias", D);
+        VEC(ln_mha_g, "norm_mha.weight", D); VEC(ln_mha_b, "norm_mha.bias", D);
+        VEC(wq, "self_attn.linear_q.weight", D, D); VEC(bq, "self_attn.linear_q.bias", D);
+        VEC(wk, "self_attn.linear_k.weight", D, D); VEC(bk, "self_attn.linear_k.bias", D);
+        VEC(wv, "self_attn.linear_v.weight", D, D); VEC(bv, "self_attn.linear_v.bias", D);
+        VEC(wo, "self_attn.linear_out.weight", D, D); VEC(bo, "self_attn.linear_out.bias", D);
+        VEC(pu, "self_attn.pos_bias_u", RNNT_H, DK); VEC(pv, "self_attn.pos_bias_v", RNNT_H, DK);
+        VEC(wpos, "self_attn.linear_pos.weight", D, D);
+        VEC(ln_conv_g, "norm_conv.weight", D); VEC(ln_conv_b, "norm_conv.bias", D);
+        VEC(pw2, "conv_module.pointwise_conv2.weight", D, D, 1); VEC(bpw2, "conv_module.pointwise_conv2.bias", D);
+        VEC(bdw, "conv_module.depthwise_conv.bias", D);
+        VEC(ln_ff_g, "norm_ff.weight", D); VEC(ln_ff_b, "norm_ff.bias", D);
+        VEC(w1, "feed_forward.w_1.weight", FF, D); VEC(b1, "feed_forward.w_1.bias", FF);
+        VEC(w2, "feed_forward.w_2.weight", D, FF); VEC(b2, "feed_forward.w_2.bias", D);
+        VEC(ln_fin_g, "norm_final.weight", D); VEC(ln_fin_b, "norm_final.bias", D);
+#undef VEC
+        NEED(p1w, p + "conv_module.pointwise_conv1.weight", 2 * D, D, 1);
+        NEED(p1b, p + "conv_module.pointwise_conv1.bias", 2 * D);
+        NEED(dww, p + "conv_module.depthwise_conv.weight", D, 1, RNNT_KDW);
+        NEED(bng, p + "conv_module.norm.weight", D);
+        NEED(bnb, p + "conv_module.norm.bias", D);
+        NEED(bnm, p + "conv_module.norm.running_mean", D);
+        NEED(bnv, p + "conv_module.norm.running_var", D);
+        // GLU pairs interleaved: row 2j = value row j, row 2j+1 = gate row 256+j (F.glu dim=1, convolution.py:139)
+        std::vector<float> p1((size_t)2 * D * D), p1bi(2 * D);
+        for (int j = 0; j < D; ++j) {
+            memcpy(&p1[(size_t)(2 * j) * D], &p1w->data[(size_t)j * D], D * sizeof(float));
+            memcpy(&p1[(size_t)(2 * j + 1) * D], &p1w->data[(size_t)(D + j) * D], D * sizeof(float));
+            p1bi[2 * j] = p1b->data[j];
+            p1bi[2 * j + 1] = p1b->data[D + j];
+            glu0[(size_t)l * D + j] = p1b->data[j] * (1.0f / (1.0f + expf(-p1b->data[D + j])));
+        }
+        putv(&w.pw1, p1);
+        putv(&w.bpw1, p1bi);
+        std::vector<float> dwt((size_t)RNNT_KDW * D), bs(D), bt(D);
+        for (int c = 0; c < D; ++c) {
+            for (int k = 0; k < RNNT_KDW; ++k) dwt[(size_t)k * D + c] = dww->data[(size_t)c * RNNT_KDW + k];
+            // BatchNorm1d eval: y = (x - mean) / sqrt(var + eps) * gamma + beta  ->  x*s + t
+            const float inv = 1.0f / sqrtf(bnv->data[c] + 1e-5f);
+            bs[c] = bng->data[c] * inv;
+            bt[c] = bnb->data[c] - bnm->data[c] * bs[c];
+        }
+        putv(&w.wdw_t, dwt);
+        putv(&w.bn_s, bs);
+        putv(&w.bn_t, bt);
+        const HostTensor* g = find(ctx, p + "norm_conv.weight");
+        const HostTensor* b = find(ctx, p + "norm_conv.bias");
+        memcpy(&lncg[(size_t)l * D], g->data.data(), D * sizeof(float));
+        memcpy(&lncb[(size_t)l * D], b->data.data(), D * sizeof(float));
+    }
+    putv(&ctx->ln_conv_g_all, lncg);
+    putv(&ctx->ln_conv_b_all, lncb);
+    putv(&ctx->glu0, glu0);
+    // --- predictor / joint ---------------------------------------------------------------------
+    NEED(emb, "predictor.embed.weight", V, D);
+    NEED(wih, "predictor.rnn.weight_ih_l0", 4 * D, D);
+    NEED(whh, "predictor.rnn.weight_hh_l0", 4 * D, D);
+    NEED(bih, "predictor.rnn.bias_ih_l0", 4 * D);
+    NEED(bhh, "predictor.rnn.bias_hh_l0", 4 * D);
+    NEED(wpr, "predictor.projection.weight", D, D);
+    NEED(bpr, "predictor.projection.bias", D);
+    NEED(wen, "joint.enc_ffn.weight", D, D);
+    NEED(ben, "joint.enc_ffn.bias", D);
+    NEED(wpf, "joint.pred_ffn.weight", D, D);
+    NEED(bpf, "joint.pred_ffn.bias", D);
+    NEED(wou, "joint.ffn_out.weight", V, D);
+    NEED(bou, "joint.ffn_out.bias", V);
+    {
+        // gate rows interleaved: row 4j+g = torch row g*256+j (gate order i,f,g,o)
+        std::vector<float> hh((size_t)4 * D * D), ih((size_t)4 * D * D), bb(4 * D);
+        for (int j = 0; j < D; ++j)
+            for (int g = 0; g < 4; ++g) {
+                memcpy(&hh[(size_t)(4 * j + g) * D], &whh->data[(size_t)(g * D + j) * D], D * sizeof(float));
+                memcpy(&ih[(size_t)(4 * j + g) * D], &wih->data[(size_t)(g * D + j) * D], D * sizeof(float));
+                bb[4 * j + g] = bih->data[g * D + j] + bhh->data[g * D + j];
+            }
+        putv(&ctx->whh_il, hh);
+        putv(&ctx->wih_il, ih);
+        putv(&ctx->b_lstm_il, bb);
+        put(&ctx->pred_embed, emb->data.data(), emb->data.size());
+        put(&ctx->wpr, wpr->data.data(), wpr->data.size()); put(&ctx->bpr, bpr->data.data(), D);
+        put(&ctx->wenc, wen->data.data(), wen->data.size()); put(&ctx->benc, ben->data.data(), D);
+        put(&ctx->wpf, wpf->data.data(), wpf->data.size()); put(&ctx->bpf, bpf->data.data(), D);
+        put(&ctx->wout, wou->data.data(), wou->data.size()); put(&ctx->bout, bou->data.data(), V);
+    }
+#undef NEED
+    // upload
+    if (ctx->blob) { (void)hipFree(ctx->blob); ctx->blob = nullptr; }
+    int rc;
+    if ((rc = dmalloc(ctx, &ctx->blob, blob.size()))) return rc;
+    ctx->blob_floats = blob.size();
+    HIPCHK(hipMemcpyAsync(ctx->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    for (auto& f : fix) *f.first = ctx->blob + f.second;
+    // derived tables on the device: P_l = pe * W_pos^T (attention.py:396, batch-invariant), input-gate
+    // table E = embed * W_ih^T + b_ih + b_hh (predictor.py:200,204)
+    for (int l = 0; l < L; ++l) {
+        if (!ctx->lw[l].ptab && (rc = dmalloc(ctx, &ctx->lw[l].ptab, (size_t)RNNT_PE_LEN * D))) return rc;
+        GemmP g = plain_gemm(ctx->pe, D, ctx->lw[l].wpos, D, nullptr, ctx->lw[l].ptab, D, RNNT_PE_LEN, D, D);
+        if ((rc = launch_gemm(ctx, s, 4, &g, 1))) return rc;
+    }
+    if (!ctx->egate && (rc = dmalloc(ctx, &ctx->egate, (size_t)V * 4 * D))) return rc;
+    {
+        GemmP g = plain_gemm(ctx->pred_embed, D, ctx->wih_il, D, ctx->b_lstm_il, ctx->egate, 4 * D, V, 4 * D, D);
+        if ((rc = launch_gemm(ctx, s, 4, &g, 1))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->numerics = numerics_mode;
+    ctx->finalized = true;
+    return RNNT_OK;
+}
+
+int rnnt_streams_reset(rnnt_ctx* ctx, int32_t n_streams, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    if (!ctx->finalized) return fail(ctx, RNNT_ERR_STATE, "weights not finalized");
+    if (n_streams < 1 || n_streams > ctx->cfg.max_streams) return fail(ctx, RNNT_ERR_ARG, "n_streams %d out of range", n_streams);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = ctx->cfg.max_streams;
+    ctx->n_streams = n_streams;
+    ctx->cache_len = 0; ctx->kv_start = 0; ctx->conv_pos = 0;
+    ctx->frames_buffered = 0; ctx->frames_decoded = 0;
+    ctx->launches = 0; ctx->greedy_steps = 0;
+    hipLaunchKernelGGL(conv_ring_init, dim3(grid_for((long long)L * B * ctx->cap * D)), dim3(256), 0, s, ctx->gring, ctx->xring, ctx->glu0, B, ctx->cap);
+    LAUNCHCHK("conv_ring_init");
+    HIPCHK(hipMemsetAsync(ctx->h, 0, (size_t)B * D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(ctx->c, 0, (size_t)B * D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(ctx->fidx, 0, B * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(ctx->nsym, 0, B * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(ctx->count, 0, B * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(ctx->n_active, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, s, ctx->tok, ctx->cfg.blank_id, (long long)B);
+    LAUNCHCHK("fill_i32");
+    return RNNT_OK;
+}
+
+int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t T, int32_t offset, int32_t required_cache_size,
+                       int32_t* frames_out, void* stream) {
+    if (!ctx || !fbank_dev) return fail(ctx, RNNT_ERR_ARG, "rnnt_encoder_chunk: null argument");
+    if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_encoder_chunk: no weights / no streams");
+    if (T < 7 || T > ctx->cfg.max_chunk_frames) return fail(ctx, RNNT_ERR_SHAPE, "chunk of %d frames outside [7, %d]", T, ctx->cfg.max_chunk_frames);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = ctx->n_streams;
+    const int tq = sub_len(T);
+    const int T2 = ctx->cache_len + tq;                 // attention_key_size (encoder.py:256)
+    const int pos_start = offset - ctx->cache_len;      // encoder.py:257
+    if (pos_start < 0 || pos_start + T2 > RNNT_PE_LEN)
+        return fail(ctx, RNNT_ERR_SHAPE, "positional window [%d, %d) outside the 5000-entry table", pos_start, pos_start + T2);
+    if (ctx->kv_start + T2 > ctx->tcap) return fail(ctx, RNNT_ERR_SHAPE, "K/V cache capacity %d exceeded", ctx->tcap);
+    if (ctx->frames_buffered + tq > ctx->fcap) return fail(ctx, RNNT_ERR_SHAPE, "encoder-frame buffer capacity %d exceeded", ctx->fcap);
+    int rc;
+    if ((rc = run_subsample(ctx, s, fbank_dev, B, T))) return rc;
+    for (int l = 0; l < L; ++l)
+        if ((rc = run_layer(ctx, s, l, B, tq, T2, ctx->kv_start, pos_start, ctx->conv_pos, nullptr))) return rc;
+    // after_norm straight into the frame buffer, then the joint's encoder projection for the new frames
+    hipLaunchKernelGGL(layer_norm, dim3((B * tq + 3) / 4), dim3(256), 0, s, ctx->x, ctx->after_g, ctx->after_b, ctx->encbuf, B * tq, tq,
+                       (long long)ctx->fstride * D, ctx->frames_buffered, (long long)D);
+    LAUNCHCHK("layer_norm");
+    {
+        GemmP g = plain_gemm(ctx->encbuf + (size_t)ctx->frames_buffered * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * tq, D, D);
+        g.a_n1 = tq; g.a_n2 = tq; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
+        g.c_n = tq; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ctx->frames_buffered; g.c_mod = BIG; g.c_s1 = D;
+        if ((rc = launch_gemm(ctx, s, 8, &g, 1))) return rc;
+    }
+    // cache bookkeeping (encoder.py:259-264,288)
+    int next_start;
+    if (required_cache_size < 0) next_start = 0;
+    else if (required_cache_size == 0) next_start = T2;
+    else next_start = T2 - required_cache_size > 0 ? T2 - required_cache_size : 0;
+    ctx->kv_start += next_start;
+    ctx->cache_len = T2 - next_start;
+    if (ctx->cache_len == 0) ctx->kv_start = 0;
+    ctx->conv_pos += tq;
+    ctx->frames_buffered += tq;
+    if (frames_out) *frames_out = tq;
+    return RNNT_OK;
+}
+
+int rnnt_greedy_decode(rnnt_ctx* ctx, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_greedy_decode: no weights / no streams");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = ctx->n_streams, V = ctx->cfg.vocab_size;
+    const int nf = ctx->frames_buffered;
+    if (nf <= ctx->frames_decoded) return RNNT_OK;
+    int rc;
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->n_active, B, 1LL);
+    LAUNCHCHK("fill_i32");
+    GreedyState st{ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->h, ctx->c, ctx->h2, ctx->c2};
+    int batch = nf - ctx->frames_decoded + 2;
+    const int max_steps = (nf - ctx->frames_decoded) * (ctx->cfg.n_steps + 1) + 1;
+    int done_steps = 0;
+    while (true) {
+        for (int it = 0; it < batch; ++it) {
+            // LSTM cell: gates = E[tok] + h * W_hh^T (predictor.py:200-204)
+            GemmP g1 = plain_gemm(ctx->h, D, ctx->whh_il, D, nullptr, ctx->h2, D, B, 4 * D, D, EPI_LSTM);
+            g1.X = ctx->egate; g1.I = ctx->tok; g1.X2 = ctx->c; g1.Y2 = ctx->c2;
+            if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+            GemmP g2 = plain_gemm(ctx->h2, D, ctx->wpr, D, ctx->bpr, ctx->pred, D, B, D, D);
+            if ((rc = launch_gemm(ctx, s, 8, &g2, 1))) return rc;
+            // z = tanh(enc_ffn(enc)[t_b] + pred_ffn(pred)) (joint.py:54-66)
+            GemmP g3 = plain_gemm(ctx->pred, D, ctx->wpf, D, ctx->bpf, ctx->z, D, B, D, D, EPI_TANH_ADD);
+            g3.X = ctx->encp; g3.I = ctx->fidx; g3.x_n = 1; g3.x_s0 = (long long)ctx->fstride * D; g3.x_s1 = D;
+            if ((rc = launch_gemm(ctx, s, 8, &g3, 1))) return rc;
+            GemmP g4 = plain_gemm(ctx->z, D, ctx->wout, D, ctx->bout, ctx->logits, ctx->vpad, B, V, D);
+            if ((rc = launch_gemm(ctx, s, 8, &g4, 1))) return rc;
+            hipLaunchKernelGGL(greedy_update, dim3(B), dim3(64), 0, s, ctx->logits, ctx->vpad, V, ctx->cfg.blank_id, ctx->cfg.n_steps, nf,
+                               ctx->cfg.max_tokens, st);
+            LAUNCHCHK("greedy_update");
+        }
+        done_steps += batch;
+        ctx->greedy_steps += batch;
+        HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (ctx->pinned[0] <= 0) break;
+        if (done_steps > max_steps) return fail(ctx, RNNT_ERR_STATE, "greedy decode did not terminate");
+        batch = 4;
+    }
+    ctx->frames_decoded = nf;
+    return RNNT_OK;
+}
+
+int rnnt_get_tokens(rnnt_ctx* ctx, int32_t* counts_host, int32_t* tokens_host, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (counts_host) HIPCHK(hipMemcpyAsync(counts_host, ctx->count, ctx->n_streams * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (tokens_host)
+        HIPCHK(hipMemcpyAsync(tokens_host, ctx->tokens, (size_t)ctx->n_streams * ctx->cfg.max_tokens * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+int rnnt_frames_consume(rnnt_ctx* ctx, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    if (ctx->frames_decoded != ctx->frames_buffered) return fail(ctx, RNNT_ERR_STATE, "undecoded frames in the buffer");
+    hipStream_t s = (hipStream_t)stream;
+    ctx->frames_buffered = 0;
+    ctx->frames_decoded = 0;
+    HIPCHK(hipMemsetAsync(ctx->fidx, 0, ctx->cfg.max_streams * sizeof(int), s));
+    return RNNT_OK;
+}
+
+int rnnt_predictor_step(rnnt_ctx* ctx, const int32_t* tokens_dev, const float* h_in, const float* c_in, int32_t rows, float* out_dev,
+                        float* h_out, float* c_out, void* stream) {
+    if (!ctx || !tokens_dev || !h_in || !c_in || !out_dev || !h_out || !c_out || rows < 1) return fail(ctx, RNNT_ERR_ARG, "rnnt_predictor_step: bad argument");
+    if (!ctx->finalized) return fail(ctx, RNNT_ERR_STATE, "weights not finalized");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    GemmP g1 = plain_gemm(h_in, D, ctx->whh_il, D, nullptr, h_out, D, rows, 4 * D, D, EPI_LSTM);
+    g1.X = ctx->egate; g1.I = tokens_dev; g1.X2 = c_in; g1.Y2 = c_out;
+    if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+    GemmP g2 = plain_gemm(h_out, D, ctx->wpr, D, ctx->bpr, out_dev, D, rows, D, D);
+    return launch_gemm(ctx, s, 8, &g2, 1);
+}
+
+int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32_t B, int32_t T, int32_t U, int32_t mode, float* logits_dev,
+               void* stream) {
+    if (!ctx || !enc_dev || !pred_dev || !logits_dev || B < 1 || T < 1 || U < 1) return fail(ctx, RNNT_ERR_ARG, "rnnt_joint: bad argument");
+    if (!ctx->finalized) return fail(ctx, RNNT_ERR_STATE, "weights not finalized");
+    hipStream_t s = (hipStream_t)stream;
+    const int V = ctx->cfg.vocab_size;
+    const size_t needf = (size_t)B * T * D + (size_t)B * U * D + (size_t)B * T * U * D;
+    if (needf > ctx->scratch_floats) return fail(ctx, RNNT_ERR_SHAPE, "joint lattice B=%d T=%d U=%d exceeds the context scratch", B, T, U);
+    float* e = ctx->scratch;
+    float* p = e + (size_t)B * T * D;
+    float* zz = p + (size_t)B * U * D;
+    int rc;
+    GemmP ge = plain_gemm(enc_dev, D, ctx->wenc, D, ctx->benc, e, D, B * T, D, D);
+    if ((rc = launch_gemm(ctx, s, 8, &ge, 1))) return rc;
+    // z[b,t,u,:] = tanh(e[b,t,:] + pred_ffn(pred[b,u,:])): rows m = (b,t,u); A row = pred[b,u]; X row = e[b,t]
+    GemmP gz = plain_gemm(pred_dev, D, ctx->wpf, D, ctx->bpf, zz, D, B * T * U, D, D, EPI_TANH_ADD);
+    gz.a_n1 = T * U; gz.a_n2 = U; gz.a_s0 = (long long)U * D; gz.a_s1 = 0; gz.a_s2 = D;
+    gz.X = e; gz.I = nullptr; gz.x_n = U; gz.x_s0 = D; gz.x_s1 = 0;   // row(m) = (m / U) * D
+    if ((rc = launch_gemm(ctx, s, 8, &gz, 1))) return rc;
+    GemmP go = plain_gemm(zz, D, ctx->wout, D, ctx->bout, logits_dev, V, B * T * U, V, D);
+    if ((rc = launch_gemm(ctx, s, 8, &go, 1))) return rc;
+    if (mode == 1) {
+        const long long rows = (long long)B * T * U;
+        hipLaunchKernelGGL(log_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits_dev, rows, V);
+        LAUNCHCHK("log_softmax_rows");
+    }
+    return RNNT_OK;
+}
+
+int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T, float* out_dev,
+                      int32_t* frames_out, void* stream) {
+    if (!ctx || !fbank_dev || !lens_host || !out_dev) return fail(ctx, RNNT_ERR_ARG, "rnnt_encoder_full: null argument");
+    if (!ctx->finalized) return fail(ctx, RNNT_ERR_STATE, "weights not finalized");
+    if (B < 1 || B > ctx->cfg.max_streams || T < 7 || T > ctx->cfg.max_chunk_frames)
+        return fail(ctx, RNNT_ERR_SHAPE, "rnnt_encoder_full: B=%d T=%d outside the context limits", B, T);
+    const int tq = sub_len(T);
+    if (tq > ctx->tcap) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_encoder_full: %d frames exceed the K/V capacity %d", tq, ctx->tcap);
+    hipStream_t s = (hipStream_t)stream;
+    // padding mask after subsampling: masks[:, :, 2::2][:, :, 2::2] (subsampling.py:228)
+    std::vector<int> kl(B);
+    for (int b = 0; b < B; ++b) {
+        const int len = lens_host[b] < T ? lens_host[b] : T;
+        const int n1 = len > 2 ? (len - 1) / 2 : 0;
+        kl[b] = n1 > 2 ? (n1 - 1) / 2 : 0;
+        if (kl[b] < 1) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_encoder_full: utterance %d too short", b);
+    }
+    HIPCHK(hipMemcpyAsync(ctx->klen, kl.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    int rc;
+    // fresh left context for the causal conv (zero pad, convolution.py:122-124); streaming state is clobbered
+    hipLaunchKernelGGL(conv_ring_init, dim3(grid_for((long long)L * ctx->cfg.max_streams * ctx->cap * D)), dim3(256), 0, s, ctx->gring, ctx->xring,
+                       ctx->glu0, ctx->cfg.max_streams, ctx->cap);
+    LAUNCHCHK("conv_ring_init");
+    const int saved = ctx->n_streams;
+    ctx->n_streams = 0;   // streaming state invalid after a full-context pass
+    (void)saved;
+    if ((rc = run_subsample(ctx, s, fbank_dev, B, T))) return rc;
+    for (int l = 0; l < L; ++l)
+        if ((rc = run_layer(ctx, s, l, B, tq, tq, 0, 0, 0, ctx->klen))) return rc;
+    hipLaunchKernelGGL(layer_norm, dim3((B * tq + 3) / 4), dim3(256), 0, s, ctx->x, ctx->after_g, ctx->after_b, out_dev, B * tq, BIG, 0LL, 0,
+                       (long long)D);
+    LAUNCHCHK("layer_norm");
+    if (frames_out) *frames_out = tq;
+    return RNNT_OK;
+}
+
+int rnnt_get_att_cache(rnnt_ctx* ctx, int32_t b, float* dst_host, int32_t* len_out, void* stream) {
+    if (!ctx || b < 0 || b >= ctx->n_streams) return fail(ctx, RNNT_ERR_ARG, "rnnt_get_att_cache: bad stream index");
+    hipStream_t s = (hipStream_t)stream;
+    if (len_out) *len_out = ctx->cache_len;
+    if (!dst_host || ctx->cache_len == 0) return RNNT_OK;
+    const long long n = (long long)L * RNNT_H * ctx->cache_len * 128;
+    hipLaunchKernelGGL(gather_att_cache, dim3(grid_for(n)), dim3(256), 0, s, ctx->kcache, ctx->vcache, ctx->scratch, b, ctx->cfg.max_streams,
+                       (long long)ctx->tcap, ctx->kv_start, ctx->cache_len);
+    LAUNCHCHK("gather_att_cache");
+    HIPCHK(hipMemcpyAsync(dst_host, ctx->scratch, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+int rnnt_get_cnn_cache(rnnt_ctx* ctx, int32_t b, float* dst_host, void* stream) {
+    if (!ctx || !dst_host || b < 0 || b >= ctx->n_streams) return fail(ctx, RNNT_ERR_ARG, "rnnt_get_cnn_cache: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gather_cnn_cache, dim3(L * RNNT_LORDER), dim3(64), 0, s, ctx->xring, ctx->ln_conv_g_all, ctx->ln_conv_b_all, ctx->scratch, b,
+                       ctx->cfg.max_streams, ctx->cap, ctx->conv_pos);
+    LAUNCHCHK("gather_cnn_cache");
+    HIPCHK(hipMemcpyAsync(dst_host, ctx->scratch, (size_t)L * D * RNNT_LORDER * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+int rnnt_get_predictor_state(rnnt_ctx* ctx, int32_t b, float* h_host, float* c_host, int32_t* last_token, void* stream) {
+    if (!ctx || b < 0 || b >= ctx->n_streams) return fail(ctx, RNNT_ERR_ARG, "rnnt_get_predictor_state: bad stream index");
+    hipStream_t s = (hipStream_t)stream;
+    if (h_host) HIPCHK(hipMemcpyAsync(h_host, ctx->h + (size_t)b * D, D * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (c_host) HIPCHK(hipMemcpyAsync(c_host, ctx->c + (size_t)b * D, D * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (last_token) HIPCHK(hipMemcpyAsync(last_token, ctx->tok + b, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+int rnnt_get_enc_frames(rnnt_ctx* ctx, float* dst_host, int32_t* frames_out, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nf = ctx->frames_buffered;
+    if (frames_out) *frames_out = nf;
+    if (!dst_host || nf == 0) return RNNT_OK;
+    HIPCHK(hipMemcpy2DAsync(dst_host, (size_t)nf * D * sizeof(float), ctx->encbuf, (size_t)ctx->fstride * D * sizeof(float),
+                            (size_t)nf * D * sizeof(float), ctx->n_streams, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+const float* rnnt_enc_frames_dev(rnnt_ctx* ctx, int32_t* frames_out, int32_t* stride_frames) {
+    if (!ctx) return nullptr;
+    if (frames_out) *frames_out = ctx->frames_buffered;
+    if (stride_frames) *stride_frames = ctx->fstride;
+    return ctx->encbuf;
+}
+
+int rnnt_get_counters(rnnt_ctx* ctx, int64_t* launches, int64_t* greedy_steps) {
+    if (!ctx) return RNNT_ERR_ARG;
+    if (launches) *launches = ctx->launches;
+    if (greedy_steps) *greedy_steps = ctx->greedy_steps;
+    return RNNT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,613 @@
+// Device kernels of the gfx950 streaming RNN-T path.  fp32 storage, exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain, see MI355X guide §3) so that greedy
+// tokens can match the reference's float32 CPU path.
+//
+// Kernel inventory (DESIGN.md §4 has the roofline per kernel):
+//   gemm32<WK>        small-M "NT" GEMM, one 32x32 output tile per workgroup, K split over WK waves,
+//                     deterministic LDS reduction, fused LayerNorm prologue and bias / SiLU / scale /
+//                     residual / GLU / LSTM-cell / joint-tanh epilogues, generalised A/C addressing
+//                     (implicit-GEMM conv2, K/V-cache append, ring buffers).
+//   conv1_relu        Conv2d(1->256,k3,s2)+ReLU, channels-last output.
+//   rel_attention     streaming rel-pos attention over the K/V cache with LDS-staged K/P/V tiles and
+//                     online softmax (one workgroup per stream x head x 16-query block).
+//   dwconv_bn_silu    causal depthwise k=31 over the post-GLU ring + folded BatchNorm + SiLU.
+//   layer_norm        row LayerNorm (norm_final / after_norm).
+//   greedy_update     argmax over the vocabulary + per-stream RNN-T greedy state machine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RNNT_D 256
+#define RNNT_H 4
+#define RNNT_DK 64
+#define RNNT_FF 1024
+#define RNNT_L 12
+#define RNNT_LORDER 30
+#define RNNT_KDW 31
+#define RNNT_IDIM 80
+#define RNNT_FSUB 19
+#define RNNT_F1 39
+#define RNNT_PE_LEN 5000
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum {
+    EPI_BIAS = 0,      // C = acc + bias
+    EPI_SILU = 1,      // C = silu(acc + bias)
+    EPI_RELU = 2,      // C = relu(acc + bias)
+    EPI_SCALE = 3,     // C = (acc + bias) * alpha
+    EPI_RESID = 4,     // C = R + alpha * (acc + bias)          (R may alias C)
+    EPI_GLU = 5,       // interleaved (a,gate) columns -> C[:, n/2] = a * sigmoid(gate)
+    EPI_LSTM = 6,      // interleaved (i,f,g,o) columns + input table row -> h', c'
+    EPI_TANH_ADD = 7,  // C = tanh(acc + bias + X[gather(m)][n])   (joint: enc_proj[t_b] + pred_proj)
+    EPI_LOGSOFTMAX_PREP = 8  // unused placeholder
+};
+
+struct GemmP {
+    const float* A;
+    const float* W;
+    const float* bias;   // [N] or null
+    float* C;
+    const float* R;      // residual (EPI_RESID)
+    const float* ln_g;   // LayerNorm prologue over K (requires K == 256, plain A rows); null = off
+    const float* ln_b;
+    int M, N, K;
+    // A row addressing: off(m) = (m / a_n1)*a_s0 + ((m % a_n1) / a_n2)*a_s1 + (m % a_n2)*a_s2
+    // K segments:       off(k) = (k / a_seg)*a_seg_stride + (k % a_seg)
+    int a_n1, a_n2;
+    long long a_s0, a_s1, a_s2;
+    int a_seg;
+    long long a_seg_stride;
+    int ldw;
+    // C addressing: off(m,n) = (m / c_n)*c_s0 + (((m % c_n) + c_r0) % c_mod)*c_s1 + n
+    int c_n, c_r0, c_mod;
+    long long c_s0, c_s1;
+    int epi;
+    float alpha;
+    // EPI_LSTM: X = input-gate table [vocab][4*D] interleaved, I = token per row, X2 = c_in [M][D],
+    //           C = h_out [M][D], Y2 = c_out [M][D]
+    // EPI_TANH_ADD: X = projected encoder frames, row(m) = (m / x_n)*x_s0 + I[m / x_n]*x_s1 (I null -> m % x_n)
+    const float* X;
+    const float* X2;
+    float* Y2;
+    const int* I;
+    int x_n;
+    long long x_s0, x_s1;
+};
+
+struct GemmBatch {
+    GemmP g[3];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm32<WK>: C[32x32 tile] = epi(A[M,K] * W[N,K]^T).  grid = (ceil(N/32), ceil(M/32), groups),
+// block = 64*WK threads.  Wave w accumulates K-slice [w*K/WK, (w+1)*K/WK) with 32x32x2 f32 MFMAs:
+// lane (i = l&31, kh = l>>5) feeds A[m0+i][k + 4*kh + e] and W[n0+i][k + 4*kh + e], e = 0..3, from
+// one float4 each (the MFMA's two k-slots are k+e and k+4+e, the same permutation on both operands).
+// Both operands are K-contiguous, so fragments come straight from global/L2 with 16-byte loads:
+// with M <= a few hundred rows no two waves of a workgroup share a fragment and LDS staging would
+// only add a round trip (guide §5, "GEMV / M <= 16" row generalised to the split-K small-M case).
+// ------------------------------------------------------------------------------------------------
+template <int WK>
+__global__ __launch_bounds__(64 * WK) void gemm32(GemmBatch gb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [WK][1024] partials (+ stats)
+    const GemmP& p = gb.g[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (m0 >= p.M || n0 >= p.N) return;
+    const int i = lane & 31, kh = lane >> 5;
+
+    int am = m0 + i;
+    if (am >= p.M) am = p.M - 1;
+    int wn = n0 + i;
+    if (wn >= p.N) wn = p.N - 1;
+    const float* arow = p.A + (long long)(am / p.a_n1) * p.a_s0 + (long long)((am % p.a_n1) / p.a_n2) * p.a_s1 +
+                        (long long)(am % p.a_n2) * p.a_s2;
+    const float* wrow = p.W + (long long)wn * p.ldw;
+
+    float mean = 0.f, rstd = 1.f;
+    const bool ln = p.ln_g != nullptr;
+    if (ln) {
+        // LayerNorm statistics of the tile's 32 rows over K = 256 (two-pass, float32).
+        float* st = smem + WK * 1024;
+        for (int r = wave; r < 32; r += WK) {
+            int rm = m0 + r;
+            if (rm >= p.M) rm = p.M - 1;
+            const float* rp = p.A + (long long)(rm / p.a_n1) * p.a_s0 + (long long)((rm % p.a_n1) / p.a_n2) * p.a_s1 +
+                              (long long)(rm % p.a_n2) * p.a_s2;
+            float4 v = *reinterpret_cast<const float4*>(rp + lane * 4);
+            float s = wave_sum(v.x + v.y + v.z + v.w);
+            float mu = s * (1.0f / 256.0f);
+            float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+            float q = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw);
+            if (lane == 0) {
+                st[r * 2] = mu;
+                st[r * 2 + 1] = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+            }
+        }
+        __syncthreads();
+        mean = st[i * 2];
+        rstd = st[i * 2 + 1];
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int ks = p.K / WK;
+    const int k0 = wave * ks;
+    const int kend = k0 + ks;
+    int k = k0;
+    for (; k + 32 <= kend; k += 32) {
+        float4 a[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k + 8 * u + 4 * kh;
+            a[u] = *reinterpret_cast<const float4*>(arow + (long long)(kk / p.a_seg) * p.a_seg_stride + (kk % p.a_seg));
+            w[u] = *reinterpret_cast<const float4*>(wrow + kk);
+        }
+        if (ln) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + 8 * u + 4 * kh;
+                const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
+                const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
+                a[u].x = (a[u].x - mean) * rstd * g.x + b.x;
+                a[u].y = (a[u].y - mean) * rstd * g.y + b.y;
+                a[u].z = (a[u].z - mean) * rstd * g.z + b.z;
+                a[u].w = (a[u].w - mean) * rstd * g.w + b.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, w[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, w[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, w[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, w[u].w, acc, 0, 0, 0);
+        }
+    }
+    for (; k + 8 <= kend; k += 8) {
+        const int kk = k + 4 * kh;
+        float4 a = *reinterpret_cast<const float4*>(arow + (long long)(kk / p.a_seg) * p.a_seg_stride + (kk % p.a_seg));
+        const float4 w = *reinterpret_cast<const float4*>(wrow + kk);
+        if (ln) {
+            const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
+            const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
+            a.x = (a.x - mean) * rstd * g.x + b.x;
+            a.y = (a.y - mean) * rstd * g.y + b.y;
+            a.z = (a.z - mean) * rstd * g.z + b.z;
+            a.w = (a.w - mean) * rstd * g.w + b.w;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    }
+
+    // split-K reduction through LDS in fixed wave order (deterministic, no atomics).
+#pragma unroll
+    for (int r = 0; r < 16; ++r) smem[wave * 1024 + r * 64 + lane] = acc[r];
+    __syncthreads();
+    constexpr int NT = 64 * WK;
+    constexpr int PER = 1024 / NT;   // WK <= 16 -> PER >= 1
+    float sums[PER > 0 ? PER : 1];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int idx = tid + e * NT;
+        float s = smem[idx];
+#pragma unroll
+        for (int w2 = 1; w2 < WK; ++w2) s += smem[w2 * 1024 + idx];
+        sums[e] = s;
+    }
+    const int epi = p.epi;
+    if (epi == EPI_GLU || epi == EPI_LSTM) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = tid + e * NT;
+            const int col = idx & 31;
+            smem[idx] = sums[e] + (p.bias ? p.bias[min(n0 + col, p.N - 1)] : 0.f);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int idx = tid + e * NT;
+        const int reg = idx >> 6, ln_ = idx & 63;
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (ln_ >> 5);
+        const int col = ln_ & 31;
+        const int m = m0 + row, n = n0 + col;
+        if (m >= p.M || n >= p.N) continue;
+        const long long crow = (long long)(m / p.c_n) * p.c_s0 + (long long)(((m % p.c_n) + p.c_r0) % p.c_mod) * p.c_s1;
+        if (epi == EPI_GLU) {
+            if (col & 1) continue;
+            const float a = smem[idx], g = smem[idx + 1];
+            p.C[crow + (n >> 1)] = a * sigmoidf_(g);
+        } else if (epi == EPI_LSTM) {
+            if (col & 3) continue;
+            const int tok = p.I[m];
+            const float4 t = *reinterpret_cast<const float4*>(p.X + (long long)tok * (4 * RNNT_D) + n);
+            const float gi = smem[idx] + t.x, gf = smem[idx + 1] + t.y, gg = smem[idx + 2] + t.z, go = smem[idx + 3] + t.w;
+            const int j = n >> 2;
+            const float cin = p.X2[(long long)m * RNNT_D + j];
+            const float c2 = sigmoidf_(gf) * cin + sigmoidf_(gi) * tanhf(gg);
+            const float h2 = sigmoidf_(go) * tanhf(c2);
+            p.C[(long long)m * RNNT_D + j] = h2;
+            p.Y2[(long long)m * RNNT_D + j] = c2;
+        } else {
+            float v = sums[e] + (p.bias ? p.bias[n] : 0.f);
+            if (epi == EPI_SILU) v = v * sigmoidf_(v);
+            else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+            else if (epi == EPI_SCALE) v = v * p.alpha;
+            else if (epi == EPI_RESID) v = p.R[crow + n] + p.alpha * v;
+            else if (epi == EPI_TANH_ADD) {
+                const int bi = m / p.x_n;
+                const int fr = p.I ? p.I[bi] : (m % p.x_n);
+                v = tanhf(v + p.X[(long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n]);
+            }
+            p.C[crow + n] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1_relu: y1[b][t][f][c] = relu(b1[c] + sum_{kh,kw} x[b][2t+kh][2f+kw] * w1[c][kh][kw])
+// (Conv2d(1,256,3,2)+ReLU, wenet/transformer/subsampling.py:189-190).  Channels-last so that the
+// conv2 implicit GEMM reads 768 contiguous floats per kernel row.  One thread per (b,t,f,c).
+// ------------------------------------------------------------------------------------------------
+__global__ void conv1_relu(const float* __restrict__ x, const float* __restrict__ w1t /*[9][256]*/,
+                           const float* __restrict__ b1, float* __restrict__ y1, int B, int T, int t1) {
+    const long long n = (long long)B * t1 * RNNT_F1 * RNNT_D;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 255);
+        long long r = id >> 8;
+        const int f = (int)(r % RNNT_F1);
+        r /= RNNT_F1;
+        const int t = (int)(r % t1);
+        const int b = (int)(r / t1);
+        const float* xp = x + ((long long)b * T + 2 * t) * RNNT_IDIM + 2 * f;
+        float acc = b1[c];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc = fmaf(xp[kh * RNNT_IDIM + kw], w1t[(kh * 3 + kw) * RNNT_D + c], acc);
+        y1[id] = fmaxf(acc, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer_norm: y[row] = LN(x[row]) over 256 columns, one wave per row, output row map like gemm C.
+// ------------------------------------------------------------------------------------------------
+__global__ void layer_norm(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                           float* __restrict__ y, int M, int c_n, long long c_s0, int c_r0, long long c_s1) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + (long long)row * RNNT_D + lane * 4);
+    const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+    const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+    const float rstd = 1.0f / sqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(b + lane * 4);
+    float4 o;
+    o.x = dx * rstd * gg.x + bb.x;
+    o.y = dy * rstd * gg.y + bb.y;
+    o.z = dz * rstd * gg.z + bb.z;
+    o.w = dw * rstd * gg.w + bb.w;
+    const long long off = (long long)(row / c_n) * c_s0 + (long long)((row % c_n) + c_r0) * c_s1;
+    *reinterpret_cast<float4*>(y + off + lane * 4) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rel_attention: RelPositionMultiHeadedAttention score/softmax/PV (attention.py:400-418,170-177)
+// for streaming chunks and full context.  grid = (B*H, ceil(tq/16)), block = 256 (4 waves).
+//   q      [B*tq, 256]            query projections (bias included)
+//   kc, vc [B][kv_stride rows][256] K / V caches; keys j = 0..T2-1 live at rows kv_start + j
+//   ptab   [5000][256]            pe * W_pos^T for this layer; key j uses row pos_start + j
+//   klen   per-stream number of valid keys (null -> T2 for all; full-context padding mask)
+// score(i,j) = ((q_i+u).k_j + (q_i+v).p_j) / 8, softmax over j, out_i = sum_j a_ij v_j.
+// Per 64-key tile: K/P/V rows staged in LDS with coalesced float4 loads; scores with lane = key;
+// online softmax per query row (wave w owns queries w, w+4, w+8, w+12); PV with lane = d.
+// ------------------------------------------------------------------------------------------------
+#define ATT_QB 16
+#define ATT_TK 64
+#define ATT_LD 68
+__global__ __launch_bounds__(256) void rel_attention(const float* __restrict__ q, const float* __restrict__ kc,
+                                                    const float* __restrict__ vc, const float* __restrict__ ptab,
+                                                    const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                    const int* __restrict__ klen, float* __restrict__ out, int tq, int T2,
+                                                    long long kv_stride, int kv_start, int pos_start) {
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_TK * ATT_LD];
+    __shared__ __attribute__((aligned(16))) float Ps[ATT_TK * ATT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_TK * RNNT_DK];
+    __shared__ __attribute__((aligned(16))) float Qu[ATT_QB * RNNT_DK];
+    __shared__ __attribute__((aligned(16))) float Qv[ATT_QB * RNNT_DK];
+    __shared__ float Pm[ATT_QB * ATT_TK];
+    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
+    const int q0 = blockIdx.y * ATT_QB;
+    const int nq = min(ATT_QB, tq - q0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = klen ? min(klen[b], T2) : T2;
+
+    for (int e = tid; e < ATT_QB * RNNT_DK; e += 256) {
+        const int iq = e >> 6, d = e & 63;
+        float qq = 0.f;
+        if (iq < nq) qq = q[((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + d];
+        Qu[e] = qq + bias_u[h * RNNT_DK + d];
+        Qv[e] = qq + bias_v[h * RNNT_DK + d];
+    }
+    float mrun[4], lrun[4], o[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        mrun[s] = -INFINITY;
+        lrun[s] = 0.f;
+        o[s] = 0.f;
+    }
+    const float* kbase = kc + ((long long)b * kv_stride + kv_start) * RNNT_D + h * RNNT_DK;
+    const float* vbase = vc + ((long long)b * kv_stride + kv_start) * RNNT_D + h * RNNT_DK;
+    const float* pbase = ptab + (long long)pos_start * RNNT_D + h * RNNT_DK;
+
+    for (int j0 = 0; j0 < nk; j0 += ATT_TK) {
+        __syncthreads();
+#pragma unroll
+        for (int mIt = 0; mIt < 4; ++mIt) {
+            const int r = (tid >> 4) + 16 * mIt, c4 = tid & 15;
+            const int j = j0 + r;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), pv = kv, vv = kv;
+            if (j < nk) {
+                kv = *reinterpret_cast<const float4*>(kbase + (long long)j * RNNT_D + c4 * 4);
+                pv = *reinterpret_cast<const float4*>(pbase + (long long)j * RNNT_D + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(vbase + (long long)j * RNNT_D + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(&Ks[r * ATT_LD + c4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&Ps[r * ATT_LD + c4 * 4]) = pv;
+            *reinterpret_cast<float4*>(&Vs[r * RNNT_DK + c4 * 4]) = vv;
+        }
+        __syncthreads();
+        // scores: lane = key
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int dc = 0; dc < 16; ++dc) {
+            const float4 k4 = *reinterpret_cast<const float4*>(&Ks[lane * ATT_LD + dc * 4]);
+            const float4 p4 = *reinterpret_cast<const float4*>(&Ps[lane * ATT_LD + dc * 4]);
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const int iq = wave + 4 * sI;
+                const float4 u4 = *reinterpret_cast<const float4*>(&Qu[iq * RNNT_DK + dc * 4]);
+                const float4 v4 = *reinterpret_cast<const float4*>(&Qv[iq * RNNT_DK + dc * 4]);
+                float t = s[sI];
+                t = fmaf(u4.x, k4.x, t);
+                t = fmaf(u4.y, k4.y, t);
+                t = fmaf(u4.z, k4.z, t);
+                t = fmaf(u4.w, k4.w, t);
+                t = fmaf(v4.x, p4.x, t);
+                t = fmaf(v4.y, p4.y, t);
+                t = fmaf(v4.z, p4.z, t);
+                t = fmaf(v4.w, p4.w, t);
+                s[sI] = t;
+            }
+        }
+        const bool valid = (j0 + lane) < nk;
+        float alpha[4];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            const float sc = valid ? s[sI] * 0.125f : -INFINITY;
+            const float mnew = fmaxf(mrun[sI], wave_max(sc));
+            const float pe_ = valid ? expf(sc - mnew) : 0.f;
+            alpha[sI] = expf(mrun[sI] - mnew);   // first tile: exp(-inf) = 0
+            lrun[sI] = lrun[sI] * alpha[sI] + wave_sum(pe_);
+            mrun[sI] = mnew;
+            Pm[(wave + 4 * sI) * ATT_TK + lane] = pe_;
+        }
+        __syncthreads();   // Pm visible (uniform trip count: nk is the same for the whole workgroup)
+        // PV: lane = d
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) o[sI] *= alpha[sI];
+        const int jn = min(ATT_TK, nk - j0);
+        for (int j = 0; j < jn; ++j) {
+            const float vj = Vs[j * RNNT_DK + lane];
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) o[sI] = fmaf(Pm[(wave + 4 * sI) * ATT_TK + j], vj, o[sI]);
+        }
+    }
+#pragma unroll
+    for (int sI = 0; sI < 4; ++sI) {
+        const int iq = wave + 4 * sI;
+        if (iq < nq) out[((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + lane] = o[sI] / lrun[sI];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dwconv_bn_silu: causal depthwise conv k=31 + BatchNorm(eval) + SiLU over the post-GLU ring
+// (convolution.py:142-145).  Padded frames of a full-context batch are not masked: the conv is causal and
+// padded keys are masked in attention, so they can never reach a valid frame.  ring g [B][cap][256]; frame (pos+r) of stream b lives at row
+// (pos + r + cap*K) % cap; the 30 frames before pos are the left context.  Also records the
+// pre-LayerNorm conv-module input rows into the xin ring (for the reference's cnn_cache view).
+//   out[m][c] = silu((bdw[c] + sum_k wdw[k][c] * g[frame pos+r-30+k][c]) * bn_s[c] + bn_t[c])
+// ------------------------------------------------------------------------------------------------
+__global__ void dwconv_bn_silu(const float* __restrict__ g, const float* __restrict__ wdw_t /*[31][256]*/,
+                               const float* __restrict__ bdw, const float* __restrict__ bn_s,
+                               const float* __restrict__ bn_t, float* __restrict__ out, int B, int tq, int cap, int pos,
+                               const float* __restrict__ xres, float* __restrict__ xring) {
+    const long long n = (long long)B * tq * RNNT_D;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 255);
+        const int m = (int)(id >> 8);
+        const int b = m / tq, r = m % tq;
+        const float* gb = g + (long long)b * cap * RNNT_D + c;
+        float acc = bdw[c];
+        const int base = pos + r - RNNT_LORDER + cap * 64;   // keep the modulo operand positive
+#pragma unroll
+        for (int k = 0; k < RNNT_KDW; ++k) acc = fmaf(wdw_t[k * RNNT_D + c], gb[(long long)((base + k) % cap) * RNNT_D], acc);
+        float v = acc * bn_s[c] + bn_t[c];
+        v = v * sigmoidf_(v);
+        out[id] = v;
+        if (xring) xring[((long long)b * cap + (pos + r) % cap) * RNNT_D + c] = xres[id];
+    }
+}
+
+// fill the 30 left-context rows of a fresh stream: g ring <- GLU(b_pw1) (zero input through the
+// biased pointwise conv, convolution.py:122-124,138-139), xin ring <- 0.
+__global__ void conv_ring_init(float* __restrict__ g, float* __restrict__ xring, const float* __restrict__ glu0 /*[L][256]*/,
+                               int B, int cap) {
+    const long long n = (long long)RNNT_L * B * cap * RNNT_D;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 255);
+        const int l = (int)(id / ((long long)B * cap * RNNT_D));
+        g[id] = glu0[l * RNNT_D + c];
+        xring[id] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy_update: one workgroup (one wave) per stream.  argmax over the vocabulary (first max index
+// on ties, like torch.argmax) then the per-stream state machine of
+// _decode_chunk_streaming_logic (online_rnnt_model.py:193-220):
+//   blank      -> next frame, symbol counter reset
+//   non-blank  -> emit, commit LSTM state (h,c <- h',c'), token <- k; after n_steps symbols on one
+//                 frame move to the next frame.
+// ------------------------------------------------------------------------------------------------
+struct GreedyState {
+    int* tok;        // [B] predictor input token
+    int* fidx;       // [B] current frame index (relative to frame-buffer start)
+    int* nsym;       // [B] symbols emitted on the current frame
+    int* count;      // [B] tokens emitted so far
+    int* tokens;     // [B][max_tokens]
+    int* n_active;   // [1] streams with frames left
+    float* h;        // [B][256] committed
+    float* c;
+    const float* h2; // [B][256] candidate
+    const float* c2;
+};
+
+__global__ __launch_bounds__(64) void greedy_update(const float* __restrict__ logits, int ldl, int vocab, int blank, int n_steps,
+                                                  int n_frames, int max_tokens, GreedyState st) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int f = st.fidx[b];
+    if (f >= n_frames) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < vocab; v += 64) {
+        const float x = logits[(long long)b * ldl + v];
+        if (x > best) {
+            best = x;
+            bi = v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (bi == blank) {
+        f += 1;
+        if (lane == 0) {
+            st.fidx[b] = f;
+            st.nsym[b] = 0;
+            if (f >= n_frames) atomicSub(st.n_active, 1);
+        }
+    } else {
+        for (int d = lane; d < RNNT_D; d += 64) {
+            st.h[b * RNNT_D + d] = st.h2[b * RNNT_D + d];
+            st.c[b * RNNT_D + d] = st.c2[b * RNNT_D + d];
+        }
+        if (lane == 0) {
+            const int cnt = st.count[b];
+            if (cnt < max_tokens) st.tokens[(long long)b * max_tokens + cnt] = bi;
+            st.count[b] = cnt + 1;
+            st.tok[b] = bi;
+            const int ns = st.nsym[b] + 1;
+            if (ns >= n_steps) {
+                st.nsym[b] = 0;
+                st.fidx[b] = f + 1;
+                if (f + 1 >= n_frames) atomicSub(st.n_active, 1);
+            } else {
+                st.nsym[b] = ns;
+            }
+        }
+    }
+}
+
+// log_softmax over the last dimension, in place, one wave per row (joint lattice mode 1).
+__global__ void log_softmax_rows(float* __restrict__ x, long long rows, int n) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = x + row * n;
+    float mx = -INFINITY;
+    for (int v = lane; v < n; v += 64) mx = fmaxf(mx, p[v]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int v = lane; v < n; v += 64) s += expf(p[v] - mx);
+    s = logf(wave_sum(s));
+    for (int v = lane; v < n; v += 64) p[v] = p[v] - mx - s;
+}
+
+// small helpers ------------------------------------------------------------------------------------
+__global__ void fill_f32(float* p, float v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_i32(int* p, int v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+// gather the reference's att_cache layout [L][H][len][128] (K|V) of one stream.
+__global__ void gather_att_cache(const float* __restrict__ kc, const float* __restrict__ vc, float* __restrict__ dst, int b, int B,
+                                 long long kv_stride, int kv_start, int len) {
+    const long long n = (long long)RNNT_L * RNNT_H * len * 128;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(id & 127);
+        long long r = id >> 7;
+        const int j = (int)(r % len);
+        r /= len;
+        const int h = (int)(r % RNNT_H);
+        const int l = (int)(r / RNNT_H);
+        const float* src = (e < 64 ? kc : vc) + (((long long)l * B + b) * kv_stride + kv_start + j) * RNNT_D + h * RNNT_DK + (e & 63);
+        dst[id] = *src;
+    }
+}
+// reference cnn_cache layout [L][1][256][30] of one stream = LayerNorm(norm_conv) of the last 30
+// conv-module input rows (zeros before stream start).  One wave per (l, frame).
+__global__ void gather_cnn_cache(const float* __restrict__ xring, const float* __restrict__ lng /*[L][256]*/,
+                                 const float* __restrict__ lnb, float* __restrict__ dst, int b, int B, int cap, int pos) {
+    const int l = blockIdx.x / RNNT_LORDER, i = blockIdx.x % RNNT_LORDER;
+    const int lane = threadIdx.x;
+    const int frame = pos - RNNT_LORDER + i;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (frame >= 0) {
+        const float* xp = xring + (((long long)l * B + b) * cap + frame % cap) * RNNT_D;
+        const float4 v = *reinterpret_cast<const float4*>(xp + lane * 4);
+        const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+        const float rstd = 1.0f / sqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
+        const float4 gg = *reinterpret_cast<const float4*>(lng + l * RNNT_D + lane * 4);
+        const float4 bb = *reinterpret_cast<const float4*>(lnb + l * RNNT_D + lane * 4);
+        o.x = dx * rstd * gg.x + bb.x;
+        o.y = dy * rstd * gg.y + bb.y;
+        o.z = dz * rstd * gg.z + bb.z;
+        o.w = dw * rstd * gg.w + bb.w;
+    }
+    float* d = dst + (long long)l * RNNT_D * RNNT_LORDER;
+    d[(lane * 4 + 0) * RNNT_LORDER + i] = o.x;
+    d[(lane * 4 + 1) * RNNT_LORDER + i] = o.y;
+    d[(lane * 4 + 2) * RNNT_LORDER + i] = o.z;
+    d[(lane * 4 + 3) * RNNT_LORDER + i] = o.w;
+}

@@ -1,0 +1,193 @@
+"""ctypes binding of librnnt_hip.so (include/rnnt_hip.h).  Fails loudly when the HIP library is
+missing or a call returns an error: there is no CPU fallback in the product path."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+c_i32, c_i64, c_f32p, c_i32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p
+
+
+class RnntConfig(ctypes.Structure):
+    _fields_ = [("max_streams", c_i32), ("max_chunk_frames", c_i32), ("max_cache_frames", c_i32),
+                ("max_enc_frames", c_i32), ("max_tokens", c_i32), ("vocab_size", c_i32), ("blank_id", c_i32),
+                ("n_steps", c_i32), ("device", c_i32)]
+
+
+# symbol -> (restype, argtypes); exactly the entry points declared in include/rnnt_hip.h
+SIGNATURES = {
+    "rnnt_create": (c_i32, [ctypes.POINTER(RnntConfig), ctypes.POINTER(c_vp)]),
+    "rnnt_destroy": (None, [c_vp]),
+    "rnnt_last_error": (ctypes.c_char_p, [c_vp]),
+    "rnnt_abi_version": (c_i32, []),
+    "rnnt_load_tensor": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i32, ctypes.POINTER(c_i64)]),
+    "rnnt_finalize_weights": (c_i32, [c_vp, c_i32, c_vp]),
+    "rnnt_streams_reset": (c_i32, [c_vp, c_i32, c_vp]),
+    "rnnt_encoder_chunk": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32p, c_vp]),
+    "rnnt_greedy_decode": (c_i32, [c_vp, c_vp]),
+    "rnnt_get_tokens": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
+    "rnnt_frames_consume": (c_i32, [c_vp, c_vp]),
+    "rnnt_predictor_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rnnt_joint": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "rnnt_encoder_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
+    "rnnt_get_att_cache": (c_i32, [c_vp, c_i32, c_vp, c_i32p, c_vp]),
+    "rnnt_get_cnn_cache": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
+    "rnnt_get_predictor_state": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32p, c_vp]),
+    "rnnt_get_enc_frames": (c_i32, [c_vp, c_vp, c_i32p, c_vp]),
+    "rnnt_enc_frames_dev": (c_vp, [c_vp, c_i32p, c_i32p]),
+    "rnnt_get_counters": (c_i32, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+}
+
+_LIB = None
+
+
+class RnntError(RuntimeError):
+    pass
+
+
+def load(build_if_needed=True):
+    """Load (building in-tree with hipcc when sources are newer) librnnt_hip.so."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.lib_path()
+    if build_if_needed and _build.needs_build() and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        _build.build()
+    if not os.path.exists(path):
+        raise RnntError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(c_vp)
+
+
+class RnntEngine:
+    """One context = one GPU = up to `max_streams` lock-stepped streams."""
+
+    def __init__(self, max_streams=1, max_chunk_frames=64, max_cache_frames=1024, max_enc_frames=1024, max_tokens=4096,
+                 vocab_size=412, blank_id=5, n_steps=10, device=0):
+        self.lib = load()
+        self.cfg = RnntConfig(max_streams, max_chunk_frames, max_cache_frames, max_enc_frames, max_tokens, vocab_size,
+                              blank_id, n_steps, device)
+        self.ctx = c_vp()
+        rc = self.lib.rnnt_create(ctypes.byref(self.cfg), ctypes.byref(self.ctx))
+        if rc != 0:
+            msg = self.lib.rnnt_last_error(self.ctx).decode() if self.ctx else "rnnt_create failed"
+            if self.ctx:
+                self.lib.rnnt_destroy(self.ctx)
+                self.ctx = c_vp()
+            raise RnntError(f"rnnt_create: {msg} (status {rc})")
+        self.n_streams = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rnnt_destroy(self.ctx)
+            self.ctx = c_vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RnntError(f"{what}: {self.lib.rnnt_last_error(self.ctx).decode()} (status {rc})")
+
+    # ---- weights ----------------------------------------------------------------------------
+    def load_state_dict(self, sd, stream=None):
+        """sd: name -> float32 numpy array or torch tensor (the reference's 504-key layout)."""
+        for name, v in sd.items():
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            if "num_batches_tracked" in name:
+                continue
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            dims = (c_i64 * max(a.ndim, 1))(*a.shape)
+            self._chk(self.lib.rnnt_load_tensor(self.ctx, name.encode(), _np_ptr(a), a.ndim, dims), f"rnnt_load_tensor({name})")
+        self._chk(self.lib.rnnt_finalize_weights(self.ctx, 0, stream), "rnnt_finalize_weights")
+
+    # ---- streaming --------------------------------------------------------------------------
+    def reset(self, n_streams, stream=None):
+        self._chk(self.lib.rnnt_streams_reset(self.ctx, n_streams, stream), "rnnt_streams_reset")
+        self.n_streams = n_streams
+
+    def encoder_chunk(self, fbank_ptr, chunk_frames, offset, required_cache_size, stream=None):
+        t = c_i32(0)
+        self._chk(self.lib.rnnt_encoder_chunk(self.ctx, fbank_ptr, chunk_frames, offset, required_cache_size, ctypes.byref(t), stream),
+                  "rnnt_encoder_chunk")
+        return t.value
+
+    def greedy_decode(self, stream=None):
+        self._chk(self.lib.rnnt_greedy_decode(self.ctx, stream), "rnnt_greedy_decode")
+
+    def frames_consume(self, stream=None):
+        self._chk(self.lib.rnnt_frames_consume(self.ctx, stream), "rnnt_frames_consume")
+
+    def token_counts(self, stream=None):
+        counts = np.zeros(self.n_streams, np.int32)
+        self._chk(self.lib.rnnt_get_tokens(self.ctx, _np_ptr(counts), None, stream), "rnnt_get_tokens")
+        return counts
+
+    def tokens(self, stream=None):
+        counts = np.zeros(self.n_streams, np.int32)
+        toks = np.zeros((self.n_streams, self.cfg.max_tokens), np.int32)
+        self._chk(self.lib.rnnt_get_tokens(self.ctx, _np_ptr(counts), _np_ptr(toks), stream), "rnnt_get_tokens")
+        if counts.max(initial=0) > self.cfg.max_tokens:
+            raise RnntError("token buffer overflow: raise max_tokens")
+        return [toks[b, :counts[b]].tolist() for b in range(self.n_streams)]
+
+    # ---- step API ---------------------------------------------------------------------------
+    def predictor_step(self, tok_ptr, h_ptr, c_ptr, rows, out_ptr, h_out_ptr, c_out_ptr, stream=None):
+        self._chk(self.lib.rnnt_predictor_step(self.ctx, tok_ptr, h_ptr, c_ptr, rows, out_ptr, h_out_ptr, c_out_ptr, stream), "rnnt_predictor_step")
+
+    def joint(self, enc_ptr, pred_ptr, B, T, U, mode, out_ptr, stream=None):
+        self._chk(self.lib.rnnt_joint(self.ctx, enc_ptr, pred_ptr, B, T, U, mode, out_ptr, stream), "rnnt_joint")
+
+    def encoder_full(self, fbank_ptr, lens, B, T, out_ptr, stream=None):
+        lens = np.ascontiguousarray(lens, np.int32)
+        t = c_i32(0)
+        self._chk(self.lib.rnnt_encoder_full(self.ctx, fbank_ptr, _np_ptr(lens), B, T, out_ptr, ctypes.byref(t), stream), "rnnt_encoder_full")
+        self.n_streams = 0
+        return t.value
+
+    # ---- state read-back ----------------------------------------------------------------------
+    def att_cache(self, b=0, stream=None):
+        n = c_i32(0)
+        self._chk(self.lib.rnnt_get_att_cache(self.ctx, b, None, ctypes.byref(n), stream), "rnnt_get_att_cache")
+        out = np.zeros((12, 4, n.value, 128), np.float32)
+        if n.value:
+            self._chk(self.lib.rnnt_get_att_cache(self.ctx, b, _np_ptr(out), ctypes.byref(n), stream), "rnnt_get_att_cache")
+        return out
+
+    def cnn_cache(self, b=0, stream=None):
+        out = np.zeros((12, 1, 256, 30), np.float32)
+        self._chk(self.lib.rnnt_get_cnn_cache(self.ctx, b, _np_ptr(out), stream), "rnnt_get_cnn_cache")
+        return out
+
+    def predictor_state(self, b=0, stream=None):
+        h, c, tok = np.zeros(256, np.float32), np.zeros(256, np.float32), c_i32(0)
+        self._chk(self.lib.rnnt_get_predictor_state(self.ctx, b, _np_ptr(h), _np_ptr(c), ctypes.byref(tok), stream), "rnnt_get_predictor_state")
+        return h, c, tok.value
+
+    def enc_frames(self, stream=None):
+        n = c_i32(0)
+        self._chk(self.lib.rnnt_get_enc_frames(self.ctx, None, ctypes.byref(n), stream), "rnnt_get_enc_frames")
+        out = np.zeros((self.n_streams, n.value, 256), np.float32)
+        if n.value:
+            self._chk(self.lib.rnnt_get_enc_frames(self.ctx, _np_ptr(out), ctypes.byref(n), stream), "rnnt_get_enc_frames")
+        return out
+
+    def counters(self):
+        a, b = c_i64(0), c_i64(0)
+        self._chk(self.lib.rnnt_get_counters(self.ctx, ctypes.byref(a), ctypes.byref(b)), "rnnt_get_counters")
+        return a.value, b.value

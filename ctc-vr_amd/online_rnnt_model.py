@@ -1,0 +1,250 @@
+"""Host-side mirror of the reference's OnlineRNNTModel (model/online_rnnt_model.py:58-671) over the
+HIP library.  Same constructor keywords, method names, argument meaning, return shapes and error
+behaviour for the streaming inference path; the arithmetic runs in librnnt_hip.so (gfx950 kernels),
+never on the CPU.  PyTorch is used only for device memory and streams.
+
+Additions over the reference (which is batch-1 only, :277-278,348-349): `StreamingBatch`, B lock-stepped
+independent streams in one context; each stream's result equals the reference's B=1 result.
+"""
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .lib import RnntEngine, RnntError
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class BeamHypothesis:
+    """model/online_rnnt_model.py:41-55."""
+
+    def __init__(self, tokens: List[int], log_prob: float, predictor_states=None):
+        self.tokens = tokens
+        self.log_prob = log_prob
+        self.predictor_states = predictor_states
+
+    def __lt__(self, other):
+        return self.log_prob < other.log_prob
+
+    def copy(self):
+        return BeamHypothesis(tokens=self.tokens.copy(), log_prob=self.log_prob, predictor_states=self.predictor_states)
+
+
+class _EncoderView:
+    """Attribute surface the reference's callers read: encoder.static_chunk_size and
+    encoder.embed.subsampling_rate (model/online_rnnt_model.py:283-287)."""
+
+    class _Embed:
+        subsampling_rate = 4
+        right_context = 6
+
+    def __init__(self, static_chunk_size):
+        self.static_chunk_size = static_chunk_size
+        self.embed = self._Embed()
+
+
+class OnlineRNNTModel:
+    """Drop-in for the streaming-inference surface of the reference class of the same name."""
+
+    def __init__(self, input_dim: int = 80, hidden_dim: int = 256, vocab_size: int = 4336, blank_id: int = 0,
+                 streaming: bool = True, static_chunk_size: int = 32, use_dynamic_chunk: bool = True,
+                 ctc_weight: float = 0.3, predictor_layers: int = 1, predictor_dropout: float = 0.1,
+                 ctc_dropout_rate: float = 0.1, rnnt_loss_clamp: float = -1.0, ignore_id: int = -1,
+                 # engine sizing (not in the reference)
+                 max_streams: int = 1, max_chunk_frames: int = 256, max_cache_frames: int = 1024,
+                 max_enc_frames: int = 1024, max_tokens: int = 8192, device: int = 0):
+        if input_dim != 80 or hidden_dim != 256 or predictor_layers != 1:
+            raise ValueError("the HIP path implements the reference's configured architecture: input_dim=80, hidden_dim=256, predictor_layers=1")
+        self.blank_id = blank_id
+        self.vocab_size = vocab_size
+        self.streaming = streaming
+        self.ctc_weight = ctc_weight
+        self.ignore_id = ignore_id
+        self.rnnt_loss_clamp = rnnt_loss_clamp
+        self.encoder_output_size = hidden_dim
+        self.encoder = _EncoderView(static_chunk_size if streaming else 0)
+        self.device = torch.device("cuda", device)
+        self._engine = RnntEngine(max_streams=max_streams, max_chunk_frames=max_chunk_frames, max_cache_frames=max_cache_frames,
+                                  max_enc_frames=max_enc_frames, max_tokens=max_tokens, vocab_size=vocab_size, blank_id=blank_id,
+                                  n_steps=10, device=device)
+        self._loaded = False
+        self._chunks_done = None          # None = reset_streaming_cache not called yet (attributes are None, :138-143)
+        self._tok_count = 0
+        self.streaming_beam_hypotheses = None
+        self._global_encoder_offset = 0
+
+    # ---- nn.Module-like plumbing ------------------------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        self._engine.load_state_dict(state_dict)
+        self._loaded = True
+
+    # ---- streaming state (model/online_rnnt_model.py:138-164) ----------------------------------------
+    def reset_streaming_cache(self, device=None):
+        self._require_loaded()
+        self._engine.reset(1, _stream_ptr())
+        self._chunks_done = 0
+        self._tok_count = 0
+        self.streaming_beam_hypotheses = None
+        self._global_encoder_offset = 0
+
+    @property
+    def streaming_att_cache(self) -> Optional[torch.Tensor]:
+        if self._chunks_done is None:
+            return None
+        if self._chunks_done == 0:
+            return torch.zeros((0, 0, 0, 0), device=self.device)
+        return torch.from_numpy(self._engine.att_cache(0, _stream_ptr())).to(self.device)
+
+    @property
+    def streaming_cnn_cache(self) -> Optional[torch.Tensor]:
+        if self._chunks_done is None:
+            return None
+        if self._chunks_done == 0:
+            return torch.zeros((0, 0, 0, 0), device=self.device)
+        return torch.from_numpy(self._engine.cnn_cache(0, _stream_ptr())).to(self.device)
+
+    @property
+    def streaming_predictor_states(self) -> Optional[List[torch.Tensor]]:
+        if not self._chunks_done:
+            return None
+        h, c, _ = self._engine.predictor_state(0, _stream_ptr())
+        return [torch.from_numpy(h).view(1, 1, 256).to(self.device), torch.from_numpy(c).view(1, 1, 256).to(self.device)]
+
+    @property
+    def streaming_last_emitted_token(self) -> int:
+        if not self._chunks_done:
+            return self.blank_id
+        return self._engine.predictor_state(0, _stream_ptr())[2]
+
+    def _require_loaded(self):
+        if not self._loaded:
+            raise RnntError("load_state_dict() must be called before streaming")
+
+    # ---- one chunk, greedy (model/online_rnnt_model.py:166-222, 346-387) -----------------------------
+    def _decode_chunk_streaming_logic(self, chunk_xs: torch.Tensor, offset: int, required_cache_size: int) -> List[int]:
+        x = chunk_xs.to(self.device, torch.float32).contiguous()
+        s = _stream_ptr()
+        self._engine.encoder_chunk(x.data_ptr(), x.size(1), offset, required_cache_size, s)
+        self._engine.greedy_decode(s)
+        toks = self._engine.tokens(s)[0]
+        new = toks[self._tok_count:]
+        self._tok_count = len(toks)
+        self._engine.frames_consume(s)
+        self._chunks_done += 1
+        return new
+
+    def process_single_chunk(self, chunk_audio: torch.Tensor, chunk_len: torch.Tensor) -> Tuple[List[int], None, None]:
+        assert self.streaming, "Model is not in streaming mode for process_single_chunk."
+        assert chunk_audio.size(0) == 1, "Single chunk processing currently supports batch size 1 only."
+        if self._chunks_done is None:
+            self.reset_streaming_cache()
+        if chunk_audio.size(1) < 7:
+            print(f"Warning: Chunk too small ({chunk_audio.size(1)} frames), skipping")
+            return [], None, None
+        subsampling_rate = self.encoder.embed.subsampling_rate
+        off = self._global_encoder_offset
+        hyp = self._decode_chunk_streaming_logic(chunk_audio, off, off)
+        self._global_encoder_offset += chunk_audio.size(1) // subsampling_rate
+        return hyp, None, None
+
+    # ---- whole utterance, greedy (model/online_rnnt_model.py:274-344) --------------------------------
+    def _utterance_chunks(self, n_frames: int, chunk_size_ms: Optional[int]):
+        sr = self.encoder.embed.subsampling_rate
+        frames = (self.encoder.static_chunk_size if self.encoder.static_chunk_size > 0 else 16) * sr
+        if chunk_size_ms is not None:
+            frames = int(chunk_size_ms / 10)
+        min_frames = max(16, sr * 4)
+        if frames < min_frames:
+            if n_frames >= min_frames:
+                frames = min_frames
+            else:
+                if n_frames < 7:
+                    return None
+                frames = n_frames
+        plan = []
+        cur = 0
+        while cur < n_frames:
+            end = min(cur + frames, n_frames)
+            if end - cur == 0:
+                break
+            if end - cur >= 7:
+                plan.append((cur, end, cur // sr))
+            cur = end
+        return plan
+
+    def streaming_inference(self, audios: torch.Tensor, audio_lens: torch.Tensor,
+                            chunk_size_ms: Optional[int] = None) -> Tuple[List[List[int]], None, None]:
+        assert self.streaming, "Model is not in streaming mode for streaming_inference."
+        assert audios.size(0) == 1, "Streaming inference currently supports batch size 1 only."
+        self.reset_streaming_cache()
+        n = int(audio_lens.item())
+        plan = self._utterance_chunks(n, chunk_size_ms)
+        if plan is None:
+            print(f"Error: Input audio too short ({n} frames) for conv layers. Skipping.")
+            return [[] for _ in range(audios.size(0))], None, None
+        full = []
+        for s, e, off in plan:
+            full.extend(self._decode_chunk_streaming_logic(audios[:, s:e, :], off, off))
+        return [full], None, None
+
+    def forward(self, audios, audio_lens, texts=None, text_lens=None):
+        if not self.streaming or texts is not None:
+            raise NotImplementedError("training / offline forward is outside the accelerated path (SURVEY.md §8a: a4,a5 only)")
+        return self.streaming_inference(audios, audio_lens)
+
+    __call__ = forward
+
+
+class StreamingBatch:
+    """B independent streams advanced in lock step through one context (not in the reference, which
+    is B=1): the chunk loop of online_rnnt_decode.py:81-117 / streaming_inference for a whole batch."""
+
+    def __init__(self, state_dict, n_streams: int, vocab_size: int = 412, blank_id: int = 5, max_chunk_frames: int = 64,
+                 max_cache_frames: int = 512, max_enc_frames: int = 512, max_tokens: int = 4096, device: int = 0):
+        self.device = torch.device("cuda", device)
+        self.n = n_streams
+        self.engine = RnntEngine(max_streams=n_streams, max_chunk_frames=max_chunk_frames, max_cache_frames=max_cache_frames,
+                                 max_enc_frames=max_enc_frames, max_tokens=max_tokens, vocab_size=vocab_size, blank_id=blank_id,
+                                 n_steps=10, device=device)
+        self.engine.load_state_dict(state_dict)
+        self.offset = 0
+
+    def reset(self):
+        self.engine.reset(self.n, _stream_ptr())
+        self.offset = 0
+
+    def process_chunk(self, chunks: torch.Tensor, decode: bool = True):
+        """chunks [B,T,80] on the device; process_single_chunk semantics for every stream."""
+        assert chunks.size(0) == self.n and chunks.is_cuda and chunks.dtype == torch.float32 and chunks.is_contiguous()
+        if chunks.size(1) < 7:
+            return None
+        s = _stream_ptr()
+        self.engine.encoder_chunk(chunks.data_ptr(), chunks.size(1), self.offset, self.offset, s)
+        self.offset += chunks.size(1) // 4
+        if decode:
+            self.engine.greedy_decode(s)
+            self.engine.frames_consume(s)
+
+    def decode_script(self, audios: torch.Tensor, chunk_frames: int, per_chunk_decode: bool = True) -> List[List[int]]:
+        """Greedy loop of online_rnnt_decode.py:81-117 over [B,T,80] equal-length utterances.
+        per_chunk_decode=False runs the encoder over all chunks first and decodes once at the end
+        (identical tokens: the greedy state machine is causal in the frame index)."""
+        from .testing import chunk_plan
+        self.reset()
+        T = audios.size(1)
+        for (a, b) in chunk_plan(T, chunk_frames):
+            self.process_chunk(audios[:, a:b, :].contiguous(), decode=per_chunk_decode)
+        if not per_chunk_decode:
+            s = _stream_ptr()
+            self.engine.greedy_decode(s)
+            self.engine.frames_consume(s)
+        return self.engine.tokens(_stream_ptr())

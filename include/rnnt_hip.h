@@ -1,0 +1,143 @@
+/*
+ * rnnt_hip.h — C ABI of librnnt_hip.so: the MI355X (gfx950) streaming RNN-Transducer
+ * inference path (chunked Conformer encoder + LSTM predictor + joint + greedy/beam step kernels).
+ *
+ * The reference (CentaureaHO/CTC-VR) has no FFI/plugin layer: its boundary for this path is the
+ * Python class OnlineRNNTModel (model/online_rnnt_model.py:58) and, one level below, WeNet's
+ * step API forward_encoder_chunk / forward_predictor_step / forward_joint_step
+ * (wenet/transducer/transducer.py:444-472).  Each entry point below names the reference
+ * function it replaces.  The Python facade in ctc-vr_amd/online_rnnt_model.py binds these
+ * symbols with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every function returns 0 on success or a
+ * negative rnnt_status; rnnt_last_error(ctx) returns a static/ctx-owned message; no exceptions
+ * cross the ABI.  The caller owns every buffer it passes; the library owns what it allocates
+ * inside a context.  "dev" pointers are HIP device pointers on the context's device; "host"
+ * pointers are ordinary host memory.  A context is confined to one host thread at a time; all
+ * work of one call is enqueued on the hipStream_t passed as `stream` (void*; NULL = default
+ * stream).  Calls that return data to the host synchronise that stream.
+ * All streams of one context advance in lock step (same chunk length per call).
+ */
+#ifndef RNNT_HIP_H
+#define RNNT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rnnt_ctx rnnt_ctx;
+
+typedef enum {
+    RNNT_OK = 0,
+    RNNT_ERR_ARG = -1,      /* bad argument / unknown tensor name                         */
+    RNNT_ERR_SHAPE = -2,    /* tensor shape or capacity mismatch                          */
+    RNNT_ERR_OOM = -3,      /* hipMalloc failed                                           */
+    RNNT_ERR_HIP = -4,      /* a HIP runtime call or kernel launch failed                 */
+    RNNT_ERR_STATE = -5     /* call sequence error (weights not finalized, no streams...) */
+} rnnt_status;
+
+/* numerics modes for rnnt_finalize_weights */
+#define RNNT_NUMERICS_FP32 0   /* fp32 storage, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
+
+typedef struct {
+    int32_t max_streams;       /* B: lock-stepped streams held by the context                     */
+    int32_t max_chunk_frames;  /* largest fbank chunk (input frames) passed to rnnt_encoder_chunk  */
+    int32_t max_cache_frames;  /* K/V cache capacity per stream, in encoder frames (<= 5000)       */
+    int32_t max_enc_frames;    /* encoder-output frame buffer per stream (frames awaiting decode)  */
+    int32_t max_tokens;        /* token buffer per stream                                          */
+    int32_t vocab_size;        /* 412 for the reference tokenizer (tokenizer/tokenizer.py:53-60)   */
+    int32_t blank_id;          /* 5                                                                */
+    int32_t n_steps;           /* max symbols per encoder frame (online_rnnt_model.py:174) = 10    */
+    int32_t device;            /* HIP device ordinal                                               */
+} rnnt_config;
+
+/* -- lifetime ------------------------------------------------------------------------------ */
+/* replaces OnlineRNNTModel.__init__ (model/online_rnnt_model.py:58-143): fixed architecture
+ * (12 Conformer blocks, D=256, H=4, FFN=1024, conv2d/4, rel_pos, causal dw k=31 + BatchNorm,
+ * Embedding+LSTM(256) predictor, add/tanh joint). */
+int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out);
+void rnnt_destroy(rnnt_ctx* ctx);
+const char* rnnt_last_error(const rnnt_ctx* ctx);
+int rnnt_abi_version(void);
+
+/* -- weights --------------------------------------------------------------------------------- */
+/* replaces load_state_dict(checkpoint['model']) (online_rnnt_decode.py:49-50): one call per
+ * entry of the reference's 504-key state dict (names as in SURVEY.md §8b), float32 host data
+ * (num_batches_tracked entries are accepted and ignored). */
+int rnnt_load_tensor(rnnt_ctx* ctx, const char* name, const float* host_data, int32_t ndim,
+                     const int64_t* dims);
+/* packs weights for the kernels (BatchNorm fold, linear_pos table pe*W_pos^T, LSTM input table,
+ * GLU/LSTM row interleave, conv2 channels-last) and uploads them.  Fails with RNNT_ERR_STATE if
+ * any required tensor is missing. */
+int rnnt_finalize_weights(rnnt_ctx* ctx, int32_t numerics_mode, void* stream);
+
+/* -- stream state ------------------------------------------------------------------------------ */
+/* replaces OnlineRNNTModel.reset_streaming_cache (model/online_rnnt_model.py:145-164) for
+ * n_streams lock-stepped streams: empty K/V cache, zero conv left-context, zero LSTM state,
+ * last token = blank, no beam, frame buffer empty. */
+int rnnt_streams_reset(rnnt_ctx* ctx, int32_t n_streams, void* stream);
+
+/* replaces encoder.forward_chunk(xs, offset, required_cache_size, att_cache, cnn_cache)
+ * (wenet/transformer/encoder.py:203-299) as called from _decode_chunk_streaming_logic
+ * (model/online_rnnt_model.py:175-181), for all streams at once.
+ *   fbank_dev  [n_streams, chunk_frames, 80] float32, device
+ *   offset, required_cache_size: the reference's arguments (estimated encoder offset; see
+ *       model/online_rnnt_model.py:364-370).
+ * K/V and conv caches live in the context.  The t' = ((T-3)/2+1-3)/2+1 output frames of every
+ * stream are appended to the context's encoder-frame buffer; *frames_out receives t'. */
+int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t chunk_frames, int32_t offset,
+                       int32_t required_cache_size, int32_t* frames_out, void* stream);
+
+/* replaces the greedy loops of _decode_chunk_streaming_logic (model/online_rnnt_model.py:183-222)
+ * over every buffered encoder frame not yet decoded, all streams in parallel, state carried in
+ * the context (LSTM [h,c], last token).  Appends to the per-stream token buffers.  Synchronises. */
+int rnnt_greedy_decode(rnnt_ctx* ctx, void* stream);
+
+/* token buffers: counts_host[n_streams] total tokens so far; tokens_host [n_streams, max_tokens]
+ * (row-major, int32).  Either pointer may be NULL.  Synchronises. */
+int rnnt_get_tokens(rnnt_ctx* ctx, int32_t* counts_host, int32_t* tokens_host, void* stream);
+
+/* drop decoded frames from the encoder-frame buffer (keeps undecoded ones). */
+int rnnt_frames_consume(rnnt_ctx* ctx, void* stream);
+
+/* -- step API (WeNet export precedent, wenet/transducer/transducer.py:444-472) ---------------- */
+/* forward_predictor_step (wenet/transducer/predictor.py:185-210): tokens_dev int32 [rows],
+ * h/c in/out float32 [rows,256] device; out_dev [rows,256]. */
+int rnnt_predictor_step(rnnt_ctx* ctx, const int32_t* tokens_dev, const float* h_in_dev,
+                        const float* c_in_dev, int32_t rows, float* out_dev, float* h_out_dev,
+                        float* c_out_dev, void* stream);
+/* TransducerJoint.forward (model/component/joint.py:48-69), lattice form:
+ * enc_dev [B,T,256], pred_dev [B,U,256] -> logits_dev [B,T,U,vocab]; mode 0 = raw logits,
+ * 1 = log_softmax over the vocabulary (online_rnnt_model.py:446-447). */
+int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32_t B, int32_t T,
+               int32_t U, int32_t mode, float* logits_dev, void* stream);
+
+/* replaces BaseEncoder.forward(xs, lens, decoding_chunk_size=-1) (full context,
+ * wenet/transformer/encoder.py:121-180).  fbank_dev [B,T,80], lens_host[B];
+ * out_dev [B,T',256]; *frames_out = T'. */
+int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B,
+                      int32_t T, float* out_dev, int32_t* frames_out, void* stream);
+
+/* -- state read-back in the reference's layouts (parity tests, facade attributes) -------------- */
+/* streaming_att_cache of one stream: [12, 4, len, 128] (K = [...,:64], V = [...,64:],
+ * wenet/transformer/encoder.py:284); *len_out = cached frames.  dst_host may be NULL to query len. */
+int rnnt_get_att_cache(rnnt_ctx* ctx, int32_t stream_idx, float* dst_host, int32_t* len_out, void* stream);
+/* streaming_cnn_cache of one stream: [12, 1, 256, 30] (wenet/transformer/convolution.py:130). */
+int rnnt_get_cnn_cache(rnnt_ctx* ctx, int32_t stream_idx, float* dst_host, void* stream);
+/* predictor state [h,c] each [256] and last token of one stream. */
+int rnnt_get_predictor_state(rnnt_ctx* ctx, int32_t stream_idx, float* h_host, float* c_host,
+                             int32_t* last_token, void* stream);
+/* buffered encoder frames [n_streams, frames, 256] starting at the oldest buffered frame. */
+int rnnt_get_enc_frames(rnnt_ctx* ctx, float* dst_host, int32_t* frames_out, void* stream);
+/* device pointer of the encoder-frame buffer [n_streams, max_enc_frames, 256] (borrowed). */
+const float* rnnt_enc_frames_dev(rnnt_ctx* ctx, int32_t* frames_out, int32_t* stride_frames);
+
+/* counters for bench/roofline: number of kernel launches and greedy steps since the last reset. */
+int rnnt_get_counters(rnnt_ctx* ctx, int64_t* launches, int64_t* greedy_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNT_HIP_H */
