@@ -52,6 +52,13 @@ def load(build_if_needed=True):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname libamdhip64.so.7).
+    # Importing torch FIRST makes the loader resolve our NEEDED libamdhip64.so.7 to that already-loaded
+    # runtime; loading ours first would pull in /opt/rocm's copy and the second runtime finds no device.
+    import torch  # noqa: F401
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tlib):
+        ctypes.CDLL(tlib, mode=ctypes.RTLD_GLOBAL)
     path = _build.lib_path()
     if build_if_needed and _build.needs_build() and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         _build.build()
