@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — streaming RNN-T greedy decode throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: 64 independent 10 s streams per GPU
+(synthetic 80-dim fbank already resident in HBM), 16-frame chunks with online_rnnt_decode.py's
+slicing/offset rules (BASELINE.json configs[1]), chunked Conformer encoder + greedy RNN-T decode, tokens
+copied back to the host after every chunk (per-chunk mode, the reference script's behaviour).  Streams
+shard across ranks with no data-path collective (weak scaling); weights are broadcast once over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import ctc_vr_amd.testing as T  # noqa: E402
+
+# launch-site tags of rnnt_profile_begin (include/rnnt_hip.h)
+TAGS = {"conv1": 1, "conv2": 2, "embed": 3, "ffn1": 4, "ffn2": 5, "qkv": 6, "attn": 7, "attn_out": 8, "pw1": 9,
+        "dwconv": 10, "pw2": 11, "enc_proj": 13, "lstm": 20, "pred_proj": 21, "joint_tanh": 22, "joint_out": 23}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def sub_len(t):
+    return ((t - 3) // 2 + 1 - 3) // 2 + 1
+
+
+def site_flops_bytes(site, B, plan):
+    """Algorithmic FLOPs (2*MAC) and bytes of all launches of one site in one step."""
+    fl = by = 0.0
+    n = 0
+    t2 = 0
+    for i, (a, b) in enumerate(plan):
+        tq = sub_len(b - a)
+        t1 = (b - a - 3) // 2 + 1
+        M = B * tq
+        kv = t2 + tq            # keys seen by this chunk
+        per = {"conv2": (2.0 * M * 19 * 256 * 2304, 4.0 * (B * t1 * 39 * 256 + 256 * 2304 + M * 19 * 256), 1),
+               "embed": (2.0 * M * 4864 * 256, 4.0 * (M * 4864 + 4864 * 256 + M * 256), 1),
+               "ffn1": (2.0 * M * 256 * 1024, 4.0 * (M * 256 + 256 * 1024 + M * 1024), 24),
+               "ffn2": (2.0 * M * 256 * 1024, 4.0 * (M * 1024 + 256 * 1024 + 2 * M * 256), 24),
+               "qkv": (2.0 * M * 256 * 768, 4.0 * (M * 256 + 3 * 256 * 256 + 3 * M * 256), 12),
+               "attn": (2.0 * B * 4 * tq * kv * 64 * 3, 4.0 * (2 * B * kv * 256 + 2 * M * 256 + kv * 256), 12),
+               "attn_out": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
+               "pw1": (2.0 * M * 256 * 512, 4.0 * (M * 256 + 512 * 256 + M * 256), 12),
+               "dwconv": (2.0 * M * 256 * 31, 4.0 * (B * (30 + tq) * 256 + 2 * M * 256), 12),
+               "pw2": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12)}
+        if site in per:
+            f, y, cnt = per[site]
+            fl += f * cnt
+            by += y * cnt
+            n += cnt
+        t2 = kv if i > 0 else 0    # first chunk's K/V are dropped (required_cache_size = 0)
+    return fl, by, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=1000, help="fbank frames per stream (10 ms each)")
+    ap.add_argument("--chunk", type=int, default=16, help="fbank frames per chunk (online_rnnt_decode.py semantics)")
+    ap.add_argument("--mode", default="per_chunk", choices=["per_chunk", "deferred"],
+                    help="per_chunk: tokens returned to the host after every chunk; deferred: one decode after the last chunk")
+    ap.add_argument("--site", default="conv2", choices=sorted(TAGS), help="launch site timed for the roofline object")
+    ap.add_argument("--cpu-streams", type=int, default=8, help="streams of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    # ---- weights: generated on rank 0, ONE RCCL broadcast of the packed blob over xGMI --------------------
+    spec = T.state_dict_spec()
+    sizes = [int(np.prod(s)) if s else 1 for _, s, _ in spec]
+    t_b0 = time.perf_counter()
+    if rank == 0:
+        sd = T.make_state_dict(0)
+        flat = np.concatenate([np.asarray(sd[n], np.float32).reshape(-1) if k != "nbt" else np.zeros(1, np.float32)
+                               for (n, _, k) in spec])
+        blob = torch.from_numpy(flat).to(dev)
+    else:
+        blob = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    bcast_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    host = blob.cpu().numpy()
+    sd_np, o = {}, 0
+    for (n, s, k), sz in zip(spec, sizes):
+        if k != "nbt":
+            sd_np[n] = host[o:o + sz].reshape(s)
+        o += sz
+    del t_b0
+
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    B = args.batch
+    plan = T.chunk_plan(args.frames, args.chunk)
+    enc_frames = sum(sub_len(b - a) for a, b in plan)
+    sb = StreamingBatch(sd_np, B, max_chunk_frames=max(b - a for a, b in plan), max_cache_frames=enc_frames + 8,
+                        max_enc_frames=enc_frames + 8, max_tokens=enc_frames * 10 + 16, device=local_rank)
+    x = torch.from_numpy(T.synth_fbank(B, args.frames, seed=1234 + rank)).to(dev).contiguous()   # inputs resident in HBM
+    per_chunk = args.mode == "per_chunk"
+
+    def step():
+        return sb.decode_script(x, args.chunk, per_chunk_decode=per_chunk)
+
+    toks = None
+    for _ in range(args.warmup):
+        toks = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    sb.engine.profile_begin(TAGS[args.site])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    site_ms, site_launches = sb.engine.profile_end()
+    launches, gsteps = sb.engine.counters()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_frames = world * B * args.frames
+    value = total_frames * args.steps / elapsed
+    syms = float(np.mean([len(t) for t in toks])) / enc_frames
+    fl, by, n_per_step = site_flops_bytes(args.site, B, plan)
+    roofline = None
+    if site_launches > 0:
+        avg_s = site_ms * 1e-3 / site_launches
+        hbm = args.site in ("attn", "dwconv")
+        if hbm:
+            ach = by / n_per_step / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": f"{args.site}", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        else:
+            ach = fl / n_per_step / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": f"gemm32 @ {args.site}", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+        roofline["avg_launch_us"] = round(avg_s * 1e6, 2)
+        roofline["launches_timed"] = int(site_launches)
+        roofline["share_of_step"] = round(site_ms * 1e-3 / elapsed, 4)
+
+    cpu = None
+    if not args.no_cpu and world == 1:
+        from oracle import rnnt_oracle as O   # CPU baseline leg ONLY (checker / baseline, never the product path)
+        sd_t = O.to_torch_sd(sd_np)
+        xc = x[:args.cpu_streams].cpu()
+        t0 = time.perf_counter()
+        ok = True
+        with torch.no_grad():
+            for b in range(xc.size(0)):
+                want, _, _ = O.decode_script_greedy(sd_t, xc[b:b + 1], args.chunk)
+                ok = ok and (want == toks[b])
+        ct = time.perf_counter() - t0
+        cpu = {"value": round(xc.size(0) * args.frames / ct, 1), "unit": "audio-frames/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{xc.size(0)} of the {B} streams x {args.frames} frames, B=1 serial (the reference cannot batch), "
+                                         f"oracle/rnnt_oracle.py torch-CPU float32",
+               "tokens_match_gpu": bool(ok)}
+
+    out = {
+        "metric": "audio-frames/sec, streaming RNN-T greedy decode",
+        "value": round(value, 1),
+        "unit": "audio-frames/s",
+        "rtfx": round(value / 100.0, 1),
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"configs[1]: batch={B}/GPU synthetic {args.frames / 100:.0f} s 80-dim fbank, streaming chunk={args.chunk} "
+                               f"(online_rnnt_decode.py semantics), greedy decode, {args.mode} token return",
+                   "streams_per_gpu": B, "frames_per_stream": args.frames, "chunk_frames": args.chunk, "chunks": len(plan),
+                   "encoder_frames_per_stream": enc_frames, "symbols_per_encoder_frame": round(syms, 3), "weights": "seeded synthetic (seed 0)",
+                   "parallelism": f"streams sharded x{world}, no data-path collective"},
+        "kernel_launches_per_step": int(launches),
+        "greedy_steps_per_step": int(gsteps),
+        "weight_broadcast_ms": round(bcast_ms, 3),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

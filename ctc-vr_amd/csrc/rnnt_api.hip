@@ -67,6 +67,10 @@ struct rnnt_ctx {
     int cache_len = 0, kv_start = 0, conv_pos = 0;
     int frames_buffered = 0, frames_decoded = 0;
     int64_t launches = 0, greedy_steps = 0;
+    // optional per-kernel-site timing with HIP events on the launch stream (bench.py roofline leg)
+    int prof_tag = -1;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -94,6 +98,26 @@ int fail(rnnt_ctx* ctx, int code, const char* fmt, ...) {
         ctx->launches++;                                                                               \
     } while (0)
 
+// launch-site tags (rnnt_profile_begin)
+enum { TAG_NONE = 0, TAG_CONV1 = 1, TAG_CONV2 = 2, TAG_EMBED = 3, TAG_FFN1 = 4, TAG_FFN2 = 5, TAG_QKV = 6, TAG_ATTN = 7, TAG_ATTN_OUT = 8,
+       TAG_PW1 = 9, TAG_DWCONV = 10, TAG_PW2 = 11, TAG_LN = 12, TAG_ENC_PROJ = 13, TAG_LSTM = 20, TAG_PRED_PROJ = 21,
+       TAG_JOINT_TANH = 22, TAG_JOINT_OUT = 23, TAG_GREEDY_UPDATE = 24 };
+
+struct ProfScope {   // records a start/stop event pair around one launch when its site is selected
+    rnnt_ctx* ctx; hipStream_t s; bool on;
+    ProfScope(rnnt_ctx* c, hipStream_t st, int tag) : ctx(c), s(st), on(c->prof_tag == tag && tag != TAG_NONE) {
+        if (on) {
+            if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); ctx->prof_ev.push_back(e); }
+            }
+            (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], s);
+        }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], s); ctx->prof_used += 2; }
+    }
+};
+
 template <typename T>
 int dmalloc(rnnt_ctx* ctx, T** p, size_t n) {
     if (hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)) != hipSuccess)
@@ -118,18 +142,61 @@ GemmP plain_gemm(const float* A, int lda, const float* W, int ldw, const float* 
     return p;
 }
 
-int launch_gemm(rnnt_ctx* ctx, hipStream_t s, int wk, const GemmP* gs, int ng) {
+inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
+
+// fast-path flags and division magics of one GEMM descriptor (gemm16's a_row_off / c_row_off)
+int prepare_gemm(rnnt_ctx* ctx, GemmP& g) {
+    g.a_plain = (g.a_n1 == BIG && g.a_n2 == BIG && g.a_seg == BIG) ? 1 : 0;
+    g.c_plain = (g.c_n == BIG && g.c_r0 == 0) ? 1 : 0;
+    auto ok = [&](long long nmax, int d) { return d == BIG || nmax * (long long)d < (1ll << 32); };
+    if (!ok(g.M, g.a_n1) || !ok(g.M, g.a_n2) || !ok(g.K, g.a_seg) || !ok(g.M, g.c_n) || !ok(g.M, g.x_n))
+        return fail(ctx, RNNT_ERR_SHAPE, "gemm index range too large for the division magics");
+    if (!g.a_plain) {
+        if (g.a_n1 == BIG) g.a_n1 = g.M > 0 ? g.M + 1 : 1;   // quotient 0, remainder m
+        if (g.a_n2 == BIG) g.a_n2 = g.M > 0 ? g.M + 1 : 1;
+        if (g.a_seg == BIG) { g.a_seg = g.K + 1; g.a_seg_stride = 0; }
+    }
+    if (!g.c_plain && g.c_n == BIG) g.c_n = g.M > 0 ? g.M + 1 : 1;
+    g.a_n1_magic = div_magic(g.a_n1); g.a_n2_magic = div_magic(g.a_n2); g.a_seg_magic = div_magic(g.a_seg);
+    g.c_n_magic = div_magic(g.c_n); g.x_n_magic = div_magic(g.x_n);
+    return RNNT_OK;
+}
+
+template <int WK, int NT>
+void launch_gemm16(hipStream_t s, const GemmBatch& gb, int maxM, int maxN, int ng) {
+    dim3 grid((maxN + 16 * NT - 1) / (16 * NT), (maxM + 15) / 16, ng);
+    hipLaunchKernelGGL((gemm16<WK, NT>), grid, dim3(64 * WK), 0, s, gb);
+}
+
+// wk > 0: gemm32 (32x32 tiles, large-M implicit-GEMM conv2); wk == 0: gemm16 with a shape heuristic
+int launch_gemm(rnnt_ctx* ctx, hipStream_t s, int wk, const GemmP* gs, int ng, int tag = TAG_NONE) {
+    ProfScope prof(ctx, s, tag);
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     int maxM = 0, maxN = 0;
     for (int i = 0; i < ng; ++i) {
         gb.g[i] = gs[i];
-        if (gs[i].K % (wk * 8) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm K=%d not divisible by %d", gs[i].K, wk * 8);
+        int rc = prepare_gemm(ctx, gb.g[i]);
+        if (rc) return rc;
         if (gs[i].ln_g && gs[i].K != 256) return fail(ctx, RNNT_ERR_SHAPE, "LayerNorm prologue needs K=256");
         maxM = gs[i].M > maxM ? gs[i].M : maxM;
         maxN = gs[i].N > maxN ? gs[i].N : maxN;
     }
     if (maxM <= 0 || maxN <= 0) return RNNT_OK;
+    if (wk == 0) {
+        const int K = gs[0].K;
+        for (int i = 0; i < ng; ++i)
+            if (gs[i].K != K) return fail(ctx, RNNT_ERR_SHAPE, "grouped gemm needs one K");
+        const bool wide = maxN >= 512 && gs[0].epi != EPI_LSTM ? true : (maxN >= 512);
+        const int wkk = K >= 1024 ? 8 : 4;
+        if (K % (wkk * 16) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm16 K=%d not divisible by %d", K, wkk * 16);
+        if (wide) { if (wkk == 8) launch_gemm16<8, 2>(s, gb, maxM, maxN, ng); else launch_gemm16<4, 2>(s, gb, maxM, maxN, ng); }
+        else { if (wkk == 8) launch_gemm16<8, 1>(s, gb, maxM, maxN, ng); else launch_gemm16<4, 1>(s, gb, maxM, maxN, ng); }
+        LAUNCHCHK("gemm16");
+        return RNNT_OK;
+    }
+    for (int i = 0; i < ng; ++i)
+        if (gs[i].K % (wk * 8) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm K=%d not divisible by %d", gs[i].K, wk * 8);
     dim3 grid((maxN + 31) / 32, (maxM + 31) / 32, ng);
     size_t lds = (size_t)(wk * 1024 + 64) * sizeof(float);
     switch (wk) {
@@ -165,10 +232,10 @@ int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv
     {
         GemmP g1 = plain_gemm(ctx->x, D, w.w1m, D, w.b1m, ctx->hbuf, FF, M, FF, D, EPI_SILU);
         g1.ln_g = w.ln_ffm_g; g1.ln_b = w.ln_ffm_b;
-        if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_FFN1))) return rc;
         GemmP g2 = plain_gemm(ctx->hbuf, FF, w.w2m, FF, w.b2m, ctx->x, D, M, D, FF, EPI_RESID, 0.5f);
         g2.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 16, &g2, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_FFN2))) return rc;
     }
     // x += linear_out(attention(LN(x)))
     {
@@ -182,14 +249,15 @@ int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv
         for (int i = 1; i < 3; ++i) {   // append the new K/V rows behind the cached ones
             g[i].c_n = tq; g[i].c_s0 = (long long)ctx->tcap * D; g[i].c_r0 = kv_row0 + (T2 - tq); g[i].c_mod = BIG; g[i].c_s1 = D;
         }
-        if ((rc = launch_gemm(ctx, s, 8, g, 3))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, g, 3, TAG_QKV))) return rc;
         dim3 grid(B * RNNT_H, (tq + ATT_QB - 1) / ATT_QB);
+        ProfScope prof(ctx, s, TAG_ATTN);
         hipLaunchKernelGGL(rel_attention, grid, dim3(256), 0, s, ctx->qbuf, kc, vc, w.ptab, w.pu, w.pv, klen_dev, ctx->abuf, tq, T2,
                            (long long)ctx->tcap, kv_row0, pos_start);
         LAUNCHCHK("rel_attention");
         GemmP go = plain_gemm(ctx->abuf, D, w.wo, D, w.bo, ctx->x, D, M, D, D, EPI_RESID, 1.0f);
         go.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 8, &go, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &go, 1, TAG_ATTN_OUT))) return rc;
     }
     // x += conv_module(LN(x))
     {
@@ -198,22 +266,23 @@ int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv
         GemmP g1 = plain_gemm(ctx->x, D, w.pw1, D, w.bpw1, gr, D, M, 2 * D, D, EPI_GLU);
         g1.ln_g = w.ln_conv_g; g1.ln_b = w.ln_conv_b;
         g1.c_n = tq; g1.c_s0 = (long long)ctx->cap * D; g1.c_r0 = ring_pos % ctx->cap; g1.c_mod = ctx->cap; g1.c_s1 = D;
-        if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_PW1))) return rc;
+        { ProfScope prof(ctx, s, TAG_DWCONV);
         hipLaunchKernelGGL(dwconv_bn_silu, dim3(grid_for((long long)M * D)), dim3(256), 0, s, gr, w.wdw_t, w.bdw, w.bn_s, w.bn_t,
-                           ctx->dbuf, B, tq, ctx->cap, ring_pos, ctx->x, xr);
+                           ctx->dbuf, B, tq, ctx->cap, ring_pos, ctx->x, xr); }
         LAUNCHCHK("dwconv_bn_silu");
         GemmP g2 = plain_gemm(ctx->dbuf, D, w.pw2, D, w.bpw2, ctx->x, D, M, D, D, EPI_RESID, 1.0f);
         g2.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 8, &g2, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_PW2))) return rc;
     }
     // x += 0.5 * FFN(LN(x)); x = LN_final(x)
     {
         GemmP g1 = plain_gemm(ctx->x, D, w.w1, D, w.b1, ctx->hbuf, FF, M, FF, D, EPI_SILU);
         g1.ln_g = w.ln_ff_g; g1.ln_b = w.ln_ff_b;
-        if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_FFN1))) return rc;
         GemmP g2 = plain_gemm(ctx->hbuf, FF, w.w2, FF, w.b2, ctx->x, D, M, D, FF, EPI_RESID, 0.5f);
         g2.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 16, &g2, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_FFN2))) return rc;
         hipLaunchKernelGGL(layer_norm, dim3((M + 3) / 4), dim3(256), 0, s, ctx->x, w.ln_fin_g, w.ln_fin_b, ctx->x, M, BIG, 0LL, 0,
                            (long long)D);
         LAUNCHCHK("layer_norm");
@@ -225,18 +294,19 @@ int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv
 int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T) {
     const int t1 = sub1_len(T), tq = sub_len(T);
     int rc;
+    { ProfScope prof(ctx, s, TAG_CONV1);
     hipLaunchKernelGGL(conv1_relu, dim3(grid_for((long long)B * t1 * RNNT_F1 * D)), dim3(256), 0, s, fbank, ctx->conv1_wt, ctx->conv1_b,
-                       ctx->y1, B, T, t1);
+                       ctx->y1, B, T, t1); }
     LAUNCHCHK("conv1_relu");
     // conv2 as implicit GEMM: rows (b,t',f), K = (kh, kw, ci) = 3 segments of 768 contiguous floats of y1
     GemmP g = plain_gemm(ctx->y1, 0, ctx->conv2_w, 2304, ctx->conv2_b, ctx->y2, D, B * tq * RNNT_FSUB, D, 2304, EPI_RELU);
     g.a_n1 = tq * RNNT_FSUB; g.a_n2 = RNNT_FSUB;
     g.a_s0 = (long long)t1 * RNNT_F1 * D; g.a_s1 = 2LL * RNNT_F1 * D; g.a_s2 = 2LL * D;
     g.a_seg = 768; g.a_seg_stride = (long long)RNNT_F1 * D;
-    if ((rc = launch_gemm(ctx, s, 8, &g, 1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;
     // Linear(4864 -> 256) * sqrt(256); y2 is [B*t', f*256 + c] (weight columns permuted to match)
     GemmP go = plain_gemm(ctx->y2, RNNT_FSUB * D, ctx->emb_w, RNNT_FSUB * D, ctx->emb_b, ctx->x, D, B * tq, D, RNNT_FSUB * D, EPI_SCALE, 16.0f);
-    if ((rc = launch_gemm(ctx, s, 16, &go, 1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &go, 1, TAG_EMBED))) return rc;
     return RNNT_OK;
 }
 
@@ -307,6 +377,7 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     for (int l = 0; l < L; ++l)
         if (ctx->lw[l].ptab) (void)hipFree(ctx->lw[l].ptab);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -494,12 +565,12 @@ int rnnt_finalize_weights(rnnt_ctx* ctx, int32_t numerics_mode, void* stream) {
     for (int l = 0; l < L; ++l) {
         if (!ctx->lw[l].ptab && (rc = dmalloc(ctx, &ctx->lw[l].ptab, (size_t)RNNT_PE_LEN * D))) return rc;
         GemmP g = plain_gemm(ctx->pe, D, ctx->lw[l].wpos, D, nullptr, ctx->lw[l].ptab, D, RNNT_PE_LEN, D, D);
-        if ((rc = launch_gemm(ctx, s, 4, &g, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g, 1))) return rc;
     }
     if (!ctx->egate && (rc = dmalloc(ctx, &ctx->egate, (size_t)V * 4 * D))) return rc;
     {
         GemmP g = plain_gemm(ctx->pred_embed, D, ctx->wih_il, D, ctx->b_lstm_il, ctx->egate, 4 * D, V, 4 * D, D);
-        if ((rc = launch_gemm(ctx, s, 4, &g, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g, 1))) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     ctx->numerics = numerics_mode;
@@ -556,7 +627,7 @@ int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t T, int32_t
         GemmP g = plain_gemm(ctx->encbuf + (size_t)ctx->frames_buffered * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * tq, D, D);
         g.a_n1 = tq; g.a_n2 = tq; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
         g.c_n = tq; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ctx->frames_buffered; g.c_mod = BIG; g.c_s1 = D;
-        if ((rc = launch_gemm(ctx, s, 8, &g, 1))) return rc;
+        if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
     }
     // cache bookkeeping (encoder.py:259-264,288)
     int next_start;
@@ -591,15 +662,15 @@ int rnnt_greedy_decode(rnnt_ctx* ctx, void* stream) {
             // LSTM cell: gates = E[tok] + h * W_hh^T (predictor.py:200-204)
             GemmP g1 = plain_gemm(ctx->h, D, ctx->whh_il, D, nullptr, ctx->h2, D, B, 4 * D, D, EPI_LSTM);
             g1.X = ctx->egate; g1.I = ctx->tok; g1.X2 = ctx->c; g1.Y2 = ctx->c2;
-            if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+            if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_LSTM))) return rc;
             GemmP g2 = plain_gemm(ctx->h2, D, ctx->wpr, D, ctx->bpr, ctx->pred, D, B, D, D);
-            if ((rc = launch_gemm(ctx, s, 8, &g2, 1))) return rc;
+            if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_PRED_PROJ))) return rc;
             // z = tanh(enc_ffn(enc)[t_b] + pred_ffn(pred)) (joint.py:54-66)
             GemmP g3 = plain_gemm(ctx->pred, D, ctx->wpf, D, ctx->bpf, ctx->z, D, B, D, D, EPI_TANH_ADD);
             g3.X = ctx->encp; g3.I = ctx->fidx; g3.x_n = 1; g3.x_s0 = (long long)ctx->fstride * D; g3.x_s1 = D;
-            if ((rc = launch_gemm(ctx, s, 8, &g3, 1))) return rc;
+            if ((rc = launch_gemm(ctx, s, 0, &g3, 1, TAG_JOINT_TANH))) return rc;
             GemmP g4 = plain_gemm(ctx->z, D, ctx->wout, D, ctx->bout, ctx->logits, ctx->vpad, B, V, D);
-            if ((rc = launch_gemm(ctx, s, 8, &g4, 1))) return rc;
+            if ((rc = launch_gemm(ctx, s, 0, &g4, 1, TAG_JOINT_OUT))) return rc;
             hipLaunchKernelGGL(greedy_update, dim3(B), dim3(64), 0, s, ctx->logits, ctx->vpad, V, ctx->cfg.blank_id, ctx->cfg.n_steps, nf,
                                ctx->cfg.max_tokens, st);
             LAUNCHCHK("greedy_update");
@@ -644,9 +715,9 @@ int rnnt_predictor_step(rnnt_ctx* ctx, const int32_t* tokens_dev, const float* h
     int rc;
     GemmP g1 = plain_gemm(h_in, D, ctx->whh_il, D, nullptr, h_out, D, rows, 4 * D, D, EPI_LSTM);
     g1.X = ctx->egate; g1.I = tokens_dev; g1.X2 = c_in; g1.Y2 = c_out;
-    if ((rc = launch_gemm(ctx, s, 8, &g1, 1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &g1, 1))) return rc;
     GemmP g2 = plain_gemm(h_out, D, ctx->wpr, D, ctx->bpr, out_dev, D, rows, D, D);
-    return launch_gemm(ctx, s, 8, &g2, 1);
+    return launch_gemm(ctx, s, 0, &g2, 1);
 }
 
 int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32_t B, int32_t T, int32_t U, int32_t mode, float* logits_dev,
@@ -662,14 +733,14 @@ int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32
     float* zz = p + (size_t)B * U * D;
     int rc;
     GemmP ge = plain_gemm(enc_dev, D, ctx->wenc, D, ctx->benc, e, D, B * T, D, D);
-    if ((rc = launch_gemm(ctx, s, 8, &ge, 1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &ge, 1))) return rc;
     // z[b,t,u,:] = tanh(e[b,t,:] + pred_ffn(pred[b,u,:])): rows m = (b,t,u); A row = pred[b,u]; X row = e[b,t]
     GemmP gz = plain_gemm(pred_dev, D, ctx->wpf, D, ctx->bpf, zz, D, B * T * U, D, D, EPI_TANH_ADD);
     gz.a_n1 = T * U; gz.a_n2 = U; gz.a_s0 = (long long)U * D; gz.a_s1 = 0; gz.a_s2 = D;
     gz.X = e; gz.I = nullptr; gz.x_n = U; gz.x_s0 = D; gz.x_s1 = 0;   // row(m) = (m / U) * D
-    if ((rc = launch_gemm(ctx, s, 8, &gz, 1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &gz, 1))) return rc;
     GemmP go = plain_gemm(zz, D, ctx->wout, D, ctx->bout, logits_dev, V, B * T * U, V, D);
-    if ((rc = launch_gemm(ctx, s, 8, &go, 1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &go, 1))) return rc;
     if (mode == 1) {
         const long long rows = (long long)B * T * U;
         hipLaunchKernelGGL(log_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits_dev, rows, V);
@@ -766,6 +837,29 @@ const float* rnnt_enc_frames_dev(rnnt_ctx* ctx, int32_t* frames_out, int32_t* st
     if (frames_out) *frames_out = ctx->frames_buffered;
     if (stride_frames) *stride_frames = ctx->fstride;
     return ctx->encbuf;
+}
+
+int rnnt_profile_begin(rnnt_ctx* ctx, int32_t tag) {
+    if (!ctx) return RNNT_ERR_ARG;
+    ctx->prof_tag = tag;
+    ctx->prof_used = 0;
+    return RNNT_OK;
+}
+
+int rnnt_profile_end(rnnt_ctx* ctx, double* total_ms, int64_t* n_launches) {
+    if (!ctx) return RNNT_ERR_ARG;
+    double tot = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        HIPCHK(hipEventSynchronize(ctx->prof_ev[i + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (n_launches) *n_launches = (int64_t)(ctx->prof_used / 2);
+    ctx->prof_tag = -1;
+    ctx->prof_used = 0;
+    return RNNT_OK;
 }
 
 int rnnt_get_counters(rnnt_ctx* ctx, int64_t* launches, int64_t* greedy_steps) {

@@ -73,11 +73,19 @@ struct GemmP {
     const int* I;
     int x_n;
     long long x_s0, x_s1;
+    // host-computed: addressing fast paths (no integer division in the kernel) and division magics
+    // (q = umulhi(n, magic), exact while n*d < 2^32; see fastdiv()).
+    int a_plain, c_plain;
+    unsigned a_n1_magic, a_n2_magic, a_seg_magic, c_n_magic, x_n_magic;
 };
 
 struct GemmBatch {
     GemmP g[3];
 };
+
+__device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {   // exact for n*d < 2^32
+    return d == 1 ? n : (int)__umulhi((unsigned)n, magic);
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -265,6 +273,211 @@ __global__ __launch_bounds__(64 * WK) void gemm32(GemmBatch gb) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm16<WK,NT>: the small-M workhorse.  One 16 x (16*NT) output tile per workgroup, K split over WK
+// waves, v_mfma_f32_16x16x4_f32 (exact f32).  fp32 MFMA is only 256 FLOP/clk/CU, so at M = 64..192
+// rows the lever is tile COUNT: 16-row tiles give 192..768 workgroups per GEMM instead of 48..192
+// and every CU gets work.  Lane (i = l&15, kq = l>>4) feeds A[m0+i][k + 4*kq + e] and
+// W[n0+16t+i][k + 4*kq + e], e = 0..3, from one float4 each (same K permutation on both operands).
+// Addressing is division-free on the plain path; the general path (implicit-GEMM conv2, K/V append,
+// rings, joint lattice) uses host-computed multiply-high magics.
+// LayerNorm prologue: 16 lanes per row compute the two-pass statistics of the tile's 16 rows in
+// parallel (one load round trip + 8 in-row shuffle steps).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long long a_row_off(const GemmP& p, int m) {
+    if (p.a_plain) return (long long)m * p.a_s2;
+    const int q1 = fastdiv(m, p.a_n1, p.a_n1_magic);
+    const int r1 = m - q1 * p.a_n1;
+    const int q2 = fastdiv(r1, p.a_n2, p.a_n2_magic);
+    const int r2 = m - fastdiv(m, p.a_n2, p.a_n2_magic) * p.a_n2;
+    return (long long)q1 * p.a_s0 + (long long)q2 * p.a_s1 + (long long)r2 * p.a_s2;
+}
+__device__ __forceinline__ long long a_k_off(const GemmP& p, int kk) {
+    if (p.a_plain) return kk;
+    const int q = fastdiv(kk, p.a_seg, p.a_seg_magic);
+    return (long long)q * p.a_seg_stride + (kk - q * p.a_seg);
+}
+__device__ __forceinline__ long long c_row_off(const GemmP& p, int m) {
+    if (p.c_plain) return (long long)m * p.c_s1;
+    const int q = fastdiv(m, p.c_n, p.c_n_magic);
+    int r = m - q * p.c_n + p.c_r0;
+    if (r >= p.c_mod) r -= p.c_mod;
+    return (long long)q * p.c_s0 + (long long)r * p.c_s1;
+}
+
+template <int WK, int NT>
+__global__ __launch_bounds__(64 * WK) void gemm16(GemmBatch gb) {
+    __shared__ __attribute__((aligned(16))) float part[WK * NT * 256];
+    __shared__ float st[32];
+    const GemmP& p = gb.g[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * (16 * NT);
+    if (m0 >= p.M || n0 >= p.N) return;
+    const int i = lane & 15, kq = lane >> 4;
+
+    const int am = min(m0 + i, p.M - 1);
+    const float* arow = p.A + a_row_off(p, am);
+    const float* wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wrow[t] = p.W + (long long)min(n0 + 16 * t + i, p.N - 1) * p.ldw;
+
+    float mean = 0.f, rstd = 1.f;
+    const bool ln = p.ln_g != nullptr;
+    if (ln) {
+        const int grp = tid >> 4, l16 = tid & 15;
+        for (int r = grp; r < 16; r += 4 * WK) {
+            const float* rp = p.A + a_row_off(p, min(m0 + r, p.M - 1));
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(rp + 4 * (l16 + 16 * j));
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+            const float mu = sm * (1.0f / 256.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = v[j].x - mu, dy = v[j].y - mu, dz = v[j].z - mu, dw = v[j].w - mu;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 16);
+            if (l16 == 0) {
+                st[r * 2] = mu;
+                st[r * 2 + 1] = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+            }
+        }
+        __syncthreads();
+        mean = st[i * 2];
+        rstd = st[i * 2 + 1];
+    }
+
+    f32x4_ acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+
+    const int ks = p.K / WK;
+    const int k0 = wave * ks, kend = k0 + ks;
+    int k = k0;
+    for (; k + 64 <= kend; k += 64) {
+        float4 a[4], w[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = k + 16 * u + 4 * kq;
+            a[u] = *reinterpret_cast<const float4*>(arow + a_k_off(p, kk));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[u][t] = *reinterpret_cast<const float4*>(wrow[t] + kk);
+        }
+        if (ln) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k + 16 * u + 4 * kq;
+                const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
+                const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
+                a[u].x = (a[u].x - mean) * rstd * g.x + b.x;
+                a[u].y = (a[u].y - mean) * rstd * g.y + b.y;
+                a[u].z = (a[u].z - mean) * rstd * g.z + b.z;
+                a[u].w = (a[u].w - mean) * rstd * g.w + b.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, w[u][t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, w[u][t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, w[u][t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, w[u][t].w, acc[t], 0, 0, 0);
+        }
+    }
+    for (; k + 16 <= kend; k += 16) {
+        const int kk = k + 4 * kq;
+        float4 a = *reinterpret_cast<const float4*>(arow + a_k_off(p, kk));
+        if (ln) {
+            const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
+            const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
+            a.x = (a.x - mean) * rstd * g.x + b.x;
+            a.y = (a.y - mean) * rstd * g.y + b.y;
+            a.z = (a.z - mean) * rstd * g.z + b.z;
+            a.w = (a.w - mean) * rstd * g.w + b.w;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 w = *reinterpret_cast<const float4*>(wrow[t] + kk);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[t], 0, 0, 0);
+        }
+    }
+
+    // deterministic split-K reduction through LDS (fixed wave order)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(wave * NT + t) * 256 + r * 64 + lane] = acc[t][r];
+    __syncthreads();
+    constexpr int NTH = 64 * WK, NEL = NT * 256;
+    const int epi = p.epi;
+    const bool paired = (epi == EPI_GLU || epi == EPI_LSTM);
+    for (int e0 = 0; e0 < NEL; e0 += NTH) {
+        const int idx = e0 + tid;
+        float sum = 0.f;
+        if (idx < NEL) {
+            sum = part[idx];
+#pragma unroll
+            for (int w2 = 1; w2 < WK; ++w2) sum += part[w2 * NEL + idx];
+        }
+        const int t = idx >> 8, rem = idx & 255;
+        const int reg = rem >> 6, ln_ = rem & 63;
+        const int row = (ln_ >> 4) * 4 + reg, col = 16 * t + (ln_ & 15);
+        const int m = m0 + row, n = n0 + col;
+        const bool inb = idx < NEL && m < p.M && n < p.N;
+        if (paired) {
+            __syncthreads();   // all partial reads of this pass done before slot 0 is overwritten
+            if (idx < NEL) part[idx] = sum + (p.bias ? p.bias[min(n, p.N - 1)] : 0.f);
+            __syncthreads();
+            if (!inb) continue;
+            if (epi == EPI_GLU) {
+                if (col & 1) continue;
+                const float a = part[idx], g = part[idx + 1];
+                p.C[c_row_off(p, m) + (n >> 1)] = a * sigmoidf_(g);
+            } else {
+                if (col & 3) continue;
+                const int tok = p.I[m];
+                const float4 tb = *reinterpret_cast<const float4*>(p.X + (long long)tok * (4 * RNNT_D) + n);
+                const float gi = part[idx] + tb.x, gf = part[idx + 1] + tb.y, gg = part[idx + 2] + tb.z, go = part[idx + 3] + tb.w;
+                const int j = n >> 2;
+                const float cin = p.X2[(long long)m * RNNT_D + j];
+                const float c2 = sigmoidf_(gf) * cin + sigmoidf_(gi) * tanhf(gg);
+                p.C[(long long)m * RNNT_D + j] = sigmoidf_(go) * tanhf(c2);
+                p.Y2[(long long)m * RNNT_D + j] = c2;
+            }
+            continue;
+        }
+        if (!inb) continue;
+        const long long crow = c_row_off(p, m);
+        float v = sum + (p.bias ? p.bias[n] : 0.f);
+        if (epi == EPI_SILU) v = v * sigmoidf_(v);
+        else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+        else if (epi == EPI_SCALE) v = v * p.alpha;
+        else if (epi == EPI_RESID) v = p.R[crow + n] + p.alpha * v;
+        else if (epi == EPI_TANH_ADD) {
+            const int bi = fastdiv(m, p.x_n, p.x_n_magic);
+            const int fr = p.I ? p.I[bi] : (m - bi * p.x_n);
+            v = tanhf(v + p.X[(long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n]);
+        }
+        p.C[crow + n] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv1_relu: y1[b][t][f][c] = relu(b1[c] + sum_{kh,kw} x[b][2t+kh][2f+kw] * w1[c][kh][kw])
 // (Conv2d(1,256,3,2)+ReLU, wenet/transformer/subsampling.py:189-190).  Channels-last so that the
@@ -309,7 +522,9 @@ __global__ void layer_norm(const float* __restrict__ x, const float* __restrict_
     o.y = dy * rstd * gg.y + bb.y;
     o.z = dz * rstd * gg.z + bb.z;
     o.w = dw * rstd * gg.w + bb.w;
-    const long long off = (long long)(row / c_n) * c_s0 + (long long)((row % c_n) + c_r0) * c_s1;
+    long long off;
+    if (c_s0 == 0) off = (long long)(row + c_r0) * c_s1;   // plain rows
+    else off = (long long)(row / c_n) * c_s0 + (long long)((row % c_n) + c_r0) * c_s1;
     *reinterpret_cast<float4*>(y + off + lane * 4) = o;
 }
 
@@ -451,9 +666,12 @@ __global__ void dwconv_bn_silu(const float* __restrict__ g, const float* __restr
         const int b = m / tq, r = m % tq;
         const float* gb = g + (long long)b * cap * RNNT_D + c;
         float acc = bdw[c];
-        const int base = pos + r - RNNT_LORDER + cap * 64;   // keep the modulo operand positive
+        int ridx = (pos + r - RNNT_LORDER + cap * 64) % cap;   // ring row of the oldest tap (operand kept positive)
 #pragma unroll
-        for (int k = 0; k < RNNT_KDW; ++k) acc = fmaf(wdw_t[k * RNNT_D + c], gb[(long long)((base + k) % cap) * RNNT_D], acc);
+        for (int k = 0; k < RNNT_KDW; ++k) {
+            acc = fmaf(wdw_t[k * RNNT_D + c], gb[(long long)ridx * RNNT_D], acc);
+            ridx = ridx + 1 == cap ? 0 : ridx + 1;
+        }
         float v = acc * bn_s[c] + bn_t[c];
         v = v * sigmoidf_(v);
         out[id] = v;

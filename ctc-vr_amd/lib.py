@@ -37,6 +37,8 @@ SIGNATURES = {
     "rnnt_get_predictor_state": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32p, c_vp]),
     "rnnt_get_enc_frames": (c_i32, [c_vp, c_vp, c_i32p, c_vp]),
     "rnnt_enc_frames_dev": (c_vp, [c_vp, c_i32p, c_i32p]),
+    "rnnt_profile_begin": (c_i32, [c_vp, c_i32]),
+    "rnnt_profile_end": (c_i32, [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
     "rnnt_get_counters": (c_i32, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
 }
 
@@ -193,6 +195,14 @@ class RnntEngine:
         if n.value:
             self._chk(self.lib.rnnt_get_enc_frames(self.ctx, _np_ptr(out), ctypes.byref(n), stream), "rnnt_get_enc_frames")
         return out
+
+    def profile_begin(self, tag):
+        self._chk(self.lib.rnnt_profile_begin(self.ctx, tag), "rnnt_profile_begin")
+
+    def profile_end(self):
+        ms, n = ctypes.c_double(0), c_i64(0)
+        self._chk(self.lib.rnnt_profile_end(self.ctx, ctypes.byref(ms), ctypes.byref(n)), "rnnt_profile_end")
+        return ms.value, n.value
 
     def counters(self):
         a, b = c_i64(0), c_i64(0)

@@ -134,6 +134,14 @@ int rnnt_get_enc_frames(rnnt_ctx* ctx, float* dst_host, int32_t* frames_out, voi
 /* device pointer of the encoder-frame buffer [n_streams, max_enc_frames, 256] (borrowed). */
 const float* rnnt_enc_frames_dev(rnnt_ctx* ctx, int32_t* frames_out, int32_t* stride_frames);
 
+/* per-launch-site timing with HIP events recorded on the launch stream (bench.py roofline leg).
+ * tag selects ONE launch site: 1 conv1, 2 conv2 (implicit GEMM), 3 embed linear, 4 FFN w_1, 5 FFN w_2, 6 QKV,
+ * 7 attention, 8 attention out-proj, 9 pointwise_conv1+GLU, 10 depthwise conv, 11 pointwise_conv2, 13 joint enc
+ * projection, 20 LSTM cell, 21 predictor projection, 22 joint pred_ffn+tanh, 23 joint ffn_out.
+ * rnnt_profile_end synchronises the recorded events and returns the summed kernel time and launch count. */
+int rnnt_profile_begin(rnnt_ctx* ctx, int32_t tag);
+int rnnt_profile_end(rnnt_ctx* ctx, double* total_ms, int64_t* n_launches);
+
 /* counters for bench/roofline: number of kernel launches and greedy steps since the last reset. */
 int rnnt_get_counters(rnnt_ctx* ctx, int64_t* launches, int64_t* greedy_steps);
 
