@@ -93,30 +93,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     # ---- weights: generated on rank 0, ONE RCCL broadcast of the packed blob over xGMI --------------------
-    spec = T.state_dict_spec()
-    sizes = [int(np.prod(s)) if s else 1 for _, s, _ in spec]
-    t_b0 = time.perf_counter()
-    if rank == 0:
-        sd = T.make_state_dict(0)
-        flat = np.concatenate([np.asarray(sd[n], np.float32).reshape(-1) if k != "nbt" else np.zeros(1, np.float32)
-                               for (n, _, k) in spec])
-        blob = torch.from_numpy(flat).to(dev)
-    else:
-        blob = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    bcast_ms = 0.0
-    if world > 1:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(blob, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-    host = blob.cpu().numpy()
-    sd_np, o = {}, 0
-    for (n, s, k), sz in zip(spec, sizes):
-        if k != "nbt":
-            sd_np[n] = host[o:o + sz].reshape(s)
-        o += sz
-    del t_b0
+    import ctc_vr_amd.dist as D
+    sd0 = T.make_state_dict(0) if rank == 0 else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sd_np = D.broadcast_state_dict(sd0, src=0, device=dev)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
 
     from ctc_vr_amd.online_rnnt_model import StreamingBatch
     B = args.batch

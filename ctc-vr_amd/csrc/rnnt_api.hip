@@ -58,6 +58,11 @@ struct rnnt_ctx {
     // decode state
     float *h = nullptr, *c = nullptr, *h2 = nullptr, *c2 = nullptr, *pred = nullptr, *z = nullptr, *logits = nullptr;
     int *tok = nullptr, *fidx = nullptr, *nsym = nullptr, *count = nullptr, *tokens = nullptr, *n_active = nullptr, *klen = nullptr;
+    // beam search: state pools [rows][n_steps+1][512] (ping-pong), per-row buffers
+    int max_rows = 0;
+    float *pool[2] = {nullptr, nullptr}, *bpred = nullptr, *bz = nullptr, *blogits = nullptr, *b_blank = nullptr, *b_toplp = nullptr;
+    int *b_tok = nullptr, *b_frame = nullptr, *b_active = nullptr, *b_steps = nullptr, *b_toptok = nullptr, *b_srcrow = nullptr, *b_srcstep = nullptr;
+    int pool_cur = 0;
     int* pinned = nullptr;   // host-pinned scratch (n_active read-back)
     float* scratch = nullptr;  // device scratch for getters / step API
     size_t scratch_floats = 0;
@@ -314,7 +319,7 @@ int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T
 
 extern "C" {
 
-int rnnt_abi_version(void) { return 1; }
+int rnnt_abi_version(void) { return 2; }
 
 const char* rnnt_last_error(const rnnt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -326,7 +331,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     *out = ctx;   // returned even on failure so the caller can read rnnt_last_error, then destroy
     if (cfg->max_streams < 1 || cfg->max_chunk_frames < 7 || cfg->max_cache_frames < 1 || cfg->max_cache_frames > RNNT_PE_LEN ||
         cfg->max_enc_frames < 1 || cfg->max_tokens < 1 || cfg->vocab_size < 2 || cfg->blank_id < 0 || cfg->blank_id >= cfg->vocab_size ||
-        cfg->n_steps < 1)
+        cfg->n_steps < 1 || cfg->max_beam < 0 || cfg->max_beam > 64)
         return fail(ctx, RNNT_ERR_ARG, "rnnt_create: bad config");
     HIPCHK(hipSetDevice(cfg->device));
     const int B = cfg->max_streams;
@@ -357,6 +362,14 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     ALLOC(pred, (size_t)B * D); ALLOC(z, (size_t)B * D); ALLOC(logits, (size_t)B * ctx->vpad);
     ALLOC(tok, B); ALLOC(fidx, B); ALLOC(nsym, B); ALLOC(count, B); ALLOC(tokens, (size_t)B * cfg->max_tokens);
     ALLOC(n_active, 4); ALLOC(klen, B);
+    if (cfg->max_beam > 0) {
+        ctx->max_rows = B * cfg->max_beam;
+        const size_t R = ctx->max_rows, NS = cfg->n_steps, KB = cfg->max_beam;
+        ALLOC(pool[0], R * (NS + 1) * 512); ALLOC(pool[1], R * (NS + 1) * 512);
+        ALLOC(bpred, R * D); ALLOC(bz, R * D); ALLOC(blogits, R * ctx->vpad);
+        ALLOC(b_blank, R * NS); ALLOC(b_toplp, R * NS * KB); ALLOC(b_toptok, R * NS * KB);
+        ALLOC(b_tok, R); ALLOC(b_frame, R); ALLOC(b_active, R); ALLOC(b_steps, R); ALLOC(b_srcrow, R); ALLOC(b_srcstep, R);
+    }
     ctx->scratch_floats = (size_t)L * RNNT_H * ctx->tcap * 128;
     if (ctx->scratch_floats < (size_t)B * ctx->fstride * D) ctx->scratch_floats = (size_t)B * ctx->fstride * D;
     ALLOC(scratch, ctx->scratch_floats);
@@ -371,7 +384,9 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     if (!ctx) return;
     void* ptrs[] = {ctx->blob, ctx->egate, ctx->y1, ctx->y2, ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf, ctx->kcache, ctx->vcache,
                     ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->h2, ctx->c2, ctx->pred, ctx->z, ctx->logits,
-                    ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch};
+                    ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch,
+                    ctx->pool[0], ctx->pool[1], ctx->bpred, ctx->bz, ctx->blogits, ctx->b_blank, ctx->b_toplp, ctx->b_toptok,
+                    ctx->b_tok, ctx->b_frame, ctx->b_active, ctx->b_steps, ctx->b_srcrow, ctx->b_srcstep};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int l = 0; l < L; ++l)
@@ -598,6 +613,10 @@ int rnnt_streams_reset(rnnt_ctx* ctx, int32_t n_streams, void* stream) {
     HIPCHK(hipMemsetAsync(ctx->n_active, 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, s, ctx->tok, ctx->cfg.blank_id, (long long)B);
     LAUNCHCHK("fill_i32");
+    if (ctx->max_rows > 0) {   // one empty hypothesis per stream with the zero LSTM state (online_rnnt_model.py:407-415)
+        ctx->pool_cur = 0;
+        HIPCHK(hipMemsetAsync(ctx->pool[0], 0, (size_t)ctx->max_rows * (ctx->cfg.n_steps + 1) * 512 * sizeof(float), s));
+    }
     return RNNT_OK;
 }
 
@@ -700,6 +719,98 @@ int rnnt_get_tokens(rnnt_ctx* ctx, int32_t* counts_host, int32_t* tokens_host, v
 int rnnt_frames_consume(rnnt_ctx* ctx, void* stream) {
     if (!ctx) return RNNT_ERR_ARG;
     if (ctx->frames_decoded != ctx->frames_buffered) return fail(ctx, RNNT_ERR_STATE, "undecoded frames in the buffer");
+    hipStream_t s = (hipStream_t)stream;
+    ctx->frames_buffered = 0;
+    ctx->frames_decoded = 0;
+    HIPCHK(hipMemsetAsync(ctx->fidx, 0, ctx->cfg.max_streams * sizeof(int), s));
+    return RNNT_OK;
+}
+
+int rnnt_beam_frame(rnnt_ctx* ctx, int32_t frame_idx, int32_t n_rows, const int32_t* row_stream_host, const int32_t* row_tok_host,
+                    int32_t beam_k, int32_t* steps_host, float* blank_lp_host, float* top_lp_host, int32_t* top_tok_host, void* stream) {
+    if (!ctx || !row_stream_host || !row_tok_host || !steps_host || !blank_lp_host || !top_lp_host || !top_tok_host)
+        return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_frame: null argument");
+    if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_beam_frame: no weights / no streams");
+    if (ctx->max_rows == 0) return fail(ctx, RNNT_ERR_STATE, "rnnt_beam_frame: context created with max_beam = 0");
+    if (n_rows < 1 || n_rows > ctx->max_rows || beam_k < 1 || beam_k > ctx->cfg.max_beam || beam_k > ctx->cfg.vocab_size - 1)
+        return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_frame: n_rows=%d beam_k=%d out of range", n_rows, beam_k);
+    if (frame_idx < 0 || frame_idx >= ctx->frames_buffered) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_frame: frame %d not buffered", frame_idx);
+    hipStream_t s = (hipStream_t)stream;
+    const int V = ctx->cfg.vocab_size, NS = ctx->cfg.n_steps, slots = NS + 1, R = n_rows;
+    std::vector<int> fr(R);
+    for (int r = 0; r < R; ++r) {
+        if (row_stream_host[r] < 0 || row_stream_host[r] >= ctx->n_streams) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_frame: bad stream index");
+        fr[r] = row_stream_host[r] * ctx->fstride + frame_idx;   // row of the projected-encoder-frame table
+    }
+    HIPCHK(hipMemcpyAsync(ctx->b_frame, fr.data(), R * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->b_tok, row_tok_host, R * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, s, ctx->b_active, 1, (long long)R);
+    LAUNCHCHK("fill_i32");
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->n_active + 1, R, 1LL);
+    LAUNCHCHK("fill_i32");
+    HIPCHK(hipMemsetAsync(ctx->b_steps, 0, R * sizeof(int), s));
+    float* pool = ctx->pool[ctx->pool_cur];
+    BeamOut bo{ctx->b_active, ctx->b_tok, ctx->b_steps, ctx->b_blank, ctx->b_toplp, ctx->b_toptok, ctx->n_active + 1};
+    int rc;
+    for (int st = 0; st < NS; ++st) {
+        float* sin = pool + (size_t)st * 512;
+        float* sout = pool + (size_t)(st + 1) * 512;
+        GemmP g1 = plain_gemm(sin, slots * 512, ctx->whh_il, D, nullptr, sout, D, R, 4 * D, D, EPI_LSTM);
+        g1.X = ctx->egate; g1.I = ctx->b_tok; g1.X2 = sin + D; g1.Y2 = sout + D; g1.lstm_ld = slots * 512;
+        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_LSTM))) return rc;
+        GemmP g2 = plain_gemm(sout, slots * 512, ctx->wpr, D, ctx->bpr, ctx->bpred, D, R, D, D);
+        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_PRED_PROJ))) return rc;
+        GemmP g3 = plain_gemm(ctx->bpred, D, ctx->wpf, D, ctx->bpf, ctx->bz, D, R, D, D, EPI_TANH_ADD);
+        g3.X = ctx->encp; g3.I = ctx->b_frame; g3.x_n = 1; g3.x_s0 = 0; g3.x_s1 = D;
+        if ((rc = launch_gemm(ctx, s, 0, &g3, 1, TAG_JOINT_TANH))) return rc;
+        GemmP g4 = plain_gemm(ctx->bz, D, ctx->wout, D, ctx->bout, ctx->blogits, ctx->vpad, R, V, D);
+        if ((rc = launch_gemm(ctx, s, 0, &g4, 1, TAG_JOINT_OUT))) return rc;
+        hipLaunchKernelGGL(beam_reduce, dim3(R), dim3(64), 0, s, ctx->blogits, ctx->vpad, V, ctx->cfg.blank_id, beam_k, st, NS, bo);
+        LAUNCHCHK("beam_reduce");
+        HIPCHK(hipMemcpyAsync(ctx->pinned + 1, ctx->n_active + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (ctx->pinned[1] <= 0) break;
+    }
+    HIPCHK(hipMemcpyAsync(steps_host, ctx->b_steps, R * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(blank_lp_host, ctx->b_blank, (size_t)R * NS * sizeof(float), hipMemcpyDeviceToHost, s));
+    // device layout of the top-k arrays is [R][NS][beam_k] with THIS call's beam_k
+    HIPCHK(hipMemcpyAsync(top_lp_host, ctx->b_toplp, (size_t)R * NS * beam_k * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(top_tok_host, ctx->b_toptok, (size_t)R * NS * beam_k * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+int rnnt_beam_select(rnnt_ctx* ctx, int32_t n_new, const int32_t* src_row_host, const int32_t* src_step_host, void* stream) {
+    if (!ctx || !src_row_host || !src_step_host) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_select: null argument");
+    if (ctx->max_rows == 0 || n_new < 1 || n_new > ctx->max_rows) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_select: n_new out of range");
+    hipStream_t s = (hipStream_t)stream;
+    const int slots = ctx->cfg.n_steps + 1;
+    for (int r = 0; r < n_new; ++r)
+        if (src_row_host[r] < 0 || src_row_host[r] >= ctx->max_rows || src_step_host[r] < 0 || src_step_host[r] >= slots)
+            return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_select: bad source slot");
+    HIPCHK(hipMemcpyAsync(ctx->b_srcrow, src_row_host, n_new * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->b_srcstep, src_step_host, n_new * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(beam_gather, dim3(n_new), dim3(128), 0, s, ctx->pool[ctx->pool_cur], ctx->pool[ctx->pool_cur ^ 1], ctx->b_srcrow, ctx->b_srcstep,
+                       n_new, slots);
+    LAUNCHCHK("beam_gather");
+    HIPCHK(hipStreamSynchronize(s));   // the host arrays may be reused by the caller
+    ctx->pool_cur ^= 1;
+    return RNNT_OK;
+}
+
+int rnnt_beam_get_states(rnnt_ctx* ctx, int32_t n_rows, float* h_host, float* c_host, void* stream) {
+    if (!ctx || !h_host || !c_host || n_rows < 1 || n_rows > ctx->max_rows) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_get_states: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pitch = (size_t)(ctx->cfg.n_steps + 1) * 512 * sizeof(float);
+    const float* pool = ctx->pool[ctx->pool_cur];
+    HIPCHK(hipMemcpy2DAsync(h_host, D * sizeof(float), pool, pitch, D * sizeof(float), n_rows, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpy2DAsync(c_host, D * sizeof(float), pool + D, pitch, D * sizeof(float), n_rows, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return RNNT_OK;
+}
+
+int rnnt_frames_discard(rnnt_ctx* ctx, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     ctx->frames_buffered = 0;
     ctx->frames_decoded = 0;

@@ -76,6 +76,7 @@ struct GemmP {
     // host-computed: addressing fast paths (no integer division in the kernel) and division magics
     // (q = umulhi(n, magic), exact while n*d < 2^32; see fastdiv()).
     int a_plain, c_plain;
+    int lstm_ld;   // EPI_LSTM: row stride (floats) of X2 / C / Y2; 0 -> 256
     unsigned a_n1_magic, a_n2_magic, a_seg_magic, c_n_magic, x_n_magic;
 };
 
@@ -455,10 +456,11 @@ __global__ __launch_bounds__(64 * WK) void gemm16(GemmBatch gb) {
                 const float4 tb = *reinterpret_cast<const float4*>(p.X + (long long)tok * (4 * RNNT_D) + n);
                 const float gi = part[idx] + tb.x, gf = part[idx + 1] + tb.y, gg = part[idx + 2] + tb.z, go = part[idx + 3] + tb.w;
                 const int j = n >> 2;
-                const float cin = p.X2[(long long)m * RNNT_D + j];
+                const long long so = (long long)m * (p.lstm_ld ? p.lstm_ld : RNNT_D) + j;
+                const float cin = p.X2[so];
                 const float c2 = sigmoidf_(gf) * cin + sigmoidf_(gi) * tanhf(gg);
-                p.C[(long long)m * RNNT_D + j] = sigmoidf_(go) * tanhf(c2);
-                p.Y2[(long long)m * RNNT_D + j] = c2;
+                p.C[so] = sigmoidf_(go) * tanhf(c2);
+                p.Y2[so] = c2;
             }
             continue;
         }
@@ -763,6 +765,90 @@ __global__ __launch_bounds__(64) void greedy_update(const float* __restrict__ lo
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// beam_reduce: one wave per hypothesis row, one step of the extension chain of
+// _decode_chunk_beam_search (online_rnnt_model.py:446-499): log_softmax statistics, blank log-prob,
+// top-k non-blank (value desc, index asc), stop test `blank >= max - 1e-6` in double (:486), else the
+// row's next predictor input is its best non-blank token.
+// ------------------------------------------------------------------------------------------------
+struct BeamOut {
+    int* active;      // [R]
+    int* tok;         // [R] predictor input token (updated when the chain continues)
+    int* steps;       // [R] steps evaluated so far
+    float* blank_lp;  // [R][n_steps]
+    float* top_lp;    // [R][n_steps][k]
+    int* top_tok;     // [R][n_steps][k]
+    int* n_active;    // [1]
+};
+
+__global__ __launch_bounds__(64) void beam_reduce(const float* __restrict__ logits, int ldl, int vocab, int blank, int k, int step,
+                                                int n_steps, BeamOut o) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (!o.active[r]) return;
+    const float* x = logits + (long long)r * ldl;
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j;
+        v[j] = idx < vocab ? x[idx] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) se += (lane + 64 * j) < vocab ? expf(v[j] - mx) : 0.f;
+    const float lse = logf(wave_sum(se));
+    const float blank_lp = (x[blank] - mx) - lse;
+    const float max_lp = (mx - mx) - lse;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j;
+        v[j] = (idx < vocab && idx != blank) ? (v[j] - mx) - lse : -INFINITY;
+    }
+    int best_tok = 0;
+    for (int t = 0; t < k; ++t) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v[j] > bv) { bv = v[j]; bi = lane + 64 * j; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((bi & 63) == lane) v[bi >> 6] = -INFINITY;   // remove the winner
+        if (lane == 0) {
+            o.top_lp[((long long)r * n_steps + step) * k + t] = bv;
+            o.top_tok[((long long)r * n_steps + step) * k + t] = bi;
+        }
+        if (t == 0) best_tok = bi;
+    }
+    if (lane == 0) {
+        o.blank_lp[(long long)r * n_steps + step] = blank_lp;
+        o.steps[r] = step + 1;
+        const bool stop = ((double)blank_lp >= (double)max_lp - 1e-6) || (step + 1 >= n_steps);
+        if (stop) {
+            o.active[r] = 0;
+            atomicSub(o.n_active, 1);
+        } else {
+            o.tok[r] = best_tok;
+        }
+    }
+}
+
+// new_pool[r][0] <- old_pool[src_row[r]][src_step[r]]  (state = [h(256) | c(256)])
+__global__ void beam_gather(const float* __restrict__ old_pool, float* __restrict__ new_pool, const int* __restrict__ src_row,
+                            const int* __restrict__ src_step, int n_new, int slots) {
+    const int r = blockIdx.x;
+    if (r >= n_new) return;
+    const float* s = old_pool + ((long long)src_row[r] * slots + src_step[r]) * 512;
+    float* d = new_pool + (long long)r * slots * 512;
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) d[i] = s[i];
 }
 
 // log_softmax over the last dimension, in place, one wave per row (joint lattice mode 1).

@@ -13,7 +13,7 @@ c_i32, c_i64, c_f32p, c_i32p, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.POIN
 class RnntConfig(ctypes.Structure):
     _fields_ = [("max_streams", c_i32), ("max_chunk_frames", c_i32), ("max_cache_frames", c_i32),
                 ("max_enc_frames", c_i32), ("max_tokens", c_i32), ("vocab_size", c_i32), ("blank_id", c_i32),
-                ("n_steps", c_i32), ("device", c_i32)]
+                ("n_steps", c_i32), ("device", c_i32), ("max_beam", c_i32)]
 
 
 # symbol -> (restype, argtypes); exactly the entry points declared in include/rnnt_hip.h
@@ -29,6 +29,10 @@ SIGNATURES = {
     "rnnt_greedy_decode": (c_i32, [c_vp, c_vp]),
     "rnnt_get_tokens": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "rnnt_frames_consume": (c_i32, [c_vp, c_vp]),
+    "rnnt_beam_frame": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rnnt_beam_select": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "rnnt_beam_get_states": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "rnnt_frames_discard": (c_i32, [c_vp, c_vp]),
     "rnnt_predictor_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rnnt_joint": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rnnt_encoder_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
@@ -83,10 +87,10 @@ class RnntEngine:
     """One context = one GPU = up to `max_streams` lock-stepped streams."""
 
     def __init__(self, max_streams=1, max_chunk_frames=64, max_cache_frames=1024, max_enc_frames=1024, max_tokens=4096,
-                 vocab_size=412, blank_id=5, n_steps=10, device=0):
+                 vocab_size=412, blank_id=5, n_steps=10, device=0, max_beam=0):
         self.lib = load()
         self.cfg = RnntConfig(max_streams, max_chunk_frames, max_cache_frames, max_enc_frames, max_tokens, vocab_size,
-                              blank_id, n_steps, device)
+                              blank_id, n_steps, device, max_beam)
         self.ctx = c_vp()
         rc = self.lib.rnnt_create(ctypes.byref(self.cfg), ctypes.byref(self.ctx))
         if rc != 0:
@@ -154,6 +158,32 @@ class RnntEngine:
         if counts.max(initial=0) > self.cfg.max_tokens:
             raise RnntError("token buffer overflow: raise max_tokens")
         return [toks[b, :counts[b]].tolist() for b in range(self.n_streams)]
+
+    # ---- beam search (device half) ------------------------------------------------------------
+    def beam_frame(self, frame_idx, row_stream, row_tok, beam_k, stream=None):
+        n, ns = len(row_stream), self.cfg.n_steps
+        rs = np.ascontiguousarray(row_stream, np.int32)
+        rt = np.ascontiguousarray(row_tok, np.int32)
+        steps = np.zeros(n, np.int32)
+        blank = np.zeros((n, ns), np.float32)
+        top_lp = np.zeros((n, ns, beam_k), np.float32)
+        top_tok = np.zeros((n, ns, beam_k), np.int32)
+        self._chk(self.lib.rnnt_beam_frame(self.ctx, frame_idx, n, _np_ptr(rs), _np_ptr(rt), beam_k, _np_ptr(steps), _np_ptr(blank),
+                                           _np_ptr(top_lp), _np_ptr(top_tok), stream), "rnnt_beam_frame")
+        return steps, blank, top_lp, top_tok
+
+    def beam_select(self, src_row, src_step, stream=None):
+        a = np.ascontiguousarray(src_row, np.int32)
+        b = np.ascontiguousarray(src_step, np.int32)
+        self._chk(self.lib.rnnt_beam_select(self.ctx, len(a), _np_ptr(a), _np_ptr(b), stream), "rnnt_beam_select")
+
+    def beam_states(self, n_rows, stream=None):
+        h, c = np.zeros((n_rows, 256), np.float32), np.zeros((n_rows, 256), np.float32)
+        self._chk(self.lib.rnnt_beam_get_states(self.ctx, n_rows, _np_ptr(h), _np_ptr(c), stream), "rnnt_beam_get_states")
+        return h, c
+
+    def frames_discard(self, stream=None):
+        self._chk(self.lib.rnnt_frames_discard(self.ctx, stream), "rnnt_frames_discard")
 
     # ---- step API ---------------------------------------------------------------------------
     def predictor_step(self, tok_ptr, h_ptr, c_ptr, rows, out_ptr, h_out_ptr, c_out_ptr, stream=None):

@@ -33,6 +33,52 @@ class BeamHypothesis:
         return BeamHypothesis(tokens=self.tokens.copy(), log_prob=self.log_prob, predictor_states=self.predictor_states)
 
 
+def beam_advance_frame(engine, frame_idx, beams, blank_id, beam_size, stream=None):
+    """Host half of one encoder frame of _decode_chunk_beam_search (model/online_rnnt_model.py:419-518) for a
+    list of per-stream beams (each a list of BeamHypothesis whose device rows are numbered in list order,
+    streams concatenated).  The device evaluates every hypothesis' extension chain (rnnt_beam_frame); here the
+    candidates are rebuilt in the reference's order (per hypothesis, per step: blank candidate, then the top-k
+    non-blank), scored in Python floats (double), sorted stably in descending order (:506), de-duplicated
+    first-wins on the token tuple (:508-516) and truncated to the beam."""
+    row_stream, row_tok = [], []
+    for b, beam in enumerate(beams):
+        for h in beam:
+            row_stream.append(b)
+            row_tok.append(h.tokens[-1] if h.tokens else blank_id)          # :429
+    k = min(beam_size, engine.cfg.vocab_size - 1)                            # :467
+    steps, blank_lp, top_lp, top_tok = engine.beam_frame(frame_idx, row_stream, row_tok, k, stream)
+    new_beams, src_row, src_step = [], [], []
+    r = 0
+    for b, beam in enumerate(beams):
+        cands = []
+        for h in beam:
+            toks, lp = list(h.tokens), h.log_prob
+            n = int(steps[r])
+            for st in range(n):
+                cands.append((toks.copy(), lp + float(blank_lp[r, st]), r, st))                 # blank: old state
+                for j in range(k):
+                    cands.append((toks + [int(top_tok[r, st, j])], lp + float(top_lp[r, st, j]), r, st + 1))
+                if st < n - 1:                                                                   # chain continued (:489-499)
+                    toks.append(int(top_tok[r, st, 0]))
+                    lp += float(top_lp[r, st, 0])
+            r += 1
+        cands.sort(key=lambda c: c[1], reverse=True)
+        uniq, seen = [], set()
+        for c in cands:
+            t = tuple(c[0])
+            if t not in seen:
+                uniq.append(c)
+                seen.add(t)
+                if len(uniq) >= beam_size:
+                    break
+        uniq = uniq[:beam_size]
+        new_beams.append([BeamHypothesis(c[0], c[1]) for c in uniq])
+        src_row.extend(c[2] for c in uniq)
+        src_step.extend(c[3] for c in uniq)
+    engine.beam_select(src_row, src_step, stream)
+    return new_beams
+
+
 class _EncoderView:
     """Attribute surface the reference's callers read: encoder.static_chunk_size and
     encoder.embed.subsampling_rate (model/online_rnnt_model.py:283-287)."""
@@ -55,7 +101,7 @@ class OnlineRNNTModel:
                  ctc_dropout_rate: float = 0.1, rnnt_loss_clamp: float = -1.0, ignore_id: int = -1,
                  # engine sizing (not in the reference)
                  max_streams: int = 1, max_chunk_frames: int = 256, max_cache_frames: int = 1024,
-                 max_enc_frames: int = 1024, max_tokens: int = 8192, device: int = 0):
+                 max_enc_frames: int = 1024, max_tokens: int = 8192, device: int = 0, max_beam: int = 8):
         if input_dim != 80 or hidden_dim != 256 or predictor_layers != 1:
             raise ValueError("the HIP path implements the reference's configured architecture: input_dim=80, hidden_dim=256, predictor_layers=1")
         self.blank_id = blank_id
@@ -69,7 +115,7 @@ class OnlineRNNTModel:
         self.device = torch.device("cuda", device)
         self._engine = RnntEngine(max_streams=max_streams, max_chunk_frames=max_chunk_frames, max_cache_frames=max_cache_frames,
                                   max_enc_frames=max_enc_frames, max_tokens=max_tokens, vocab_size=vocab_size, blank_id=blank_id,
-                                  n_steps=10, device=device)
+                                  n_steps=10, device=device, max_beam=max_beam)
         self._loaded = False
         self._chunks_done = None          # None = reset_streaming_cache not called yet (attributes are None, :138-143)
         self._tok_count = 0
@@ -196,6 +242,55 @@ class OnlineRNNTModel:
             full.extend(self._decode_chunk_streaming_logic(audios[:, s:e, :], off, off))
         return [full], None, None
 
+    # ---- beam search (model/online_rnnt_model.py:389-645) -------------------------------------------
+    def _decode_chunk_beam_search(self, chunk_xs: torch.Tensor, offset: int, required_cache_size: int,
+                                  beam_hypotheses_in: Optional[List[BeamHypothesis]], beam_size: int = 4) -> List[BeamHypothesis]:
+        x = chunk_xs.to(self.device, torch.float32).contiguous()
+        s = _stream_ptr()
+        tq = self._engine.encoder_chunk(x.data_ptr(), x.size(1), offset, required_cache_size, s)
+        beam = beam_hypotheses_in
+        if beam is None:
+            beam = [BeamHypothesis(tokens=[], log_prob=0.0)]                 # :407-415 (zero LSTM state = fresh pool row 0)
+        for t in range(tq):
+            beam = beam_advance_frame(self._engine, t, [beam], self.blank_id, beam_size, s)[0]
+        h, c = self._engine.beam_states(len(beam), s)
+        for i, hyp in enumerate(beam):
+            hyp.predictor_states = [torch.from_numpy(h[i]).view(1, 1, 256).to(self.device),
+                                    torch.from_numpy(c[i]).view(1, 1, 256).to(self.device)]
+        self._engine.frames_discard(s)
+        self._chunks_done += 1
+        return beam
+
+    def process_single_chunk_beam_search(self, chunk_audio: torch.Tensor, chunk_len: torch.Tensor,
+                                         beam_size: int = 4) -> Tuple[List[BeamHypothesis], None, None]:
+        assert self.streaming, "Model is not in streaming mode for process_single_chunk_beam_search."
+        assert chunk_audio.size(0) == 1, "Single chunk beam search currently supports batch size 1 only."
+        if self._chunks_done is None:
+            self.reset_streaming_cache()
+        if chunk_audio.size(1) < 7:
+            print(f"Warning: Chunk too small ({chunk_audio.size(1)} frames), skipping")
+            return self.streaming_beam_hypotheses or [], None, None
+        off = self._global_encoder_offset
+        self.streaming_beam_hypotheses = self._decode_chunk_beam_search(chunk_audio, off, off, self.streaming_beam_hypotheses, beam_size)
+        self._global_encoder_offset += chunk_audio.size(1) // self.encoder.embed.subsampling_rate
+        return self.streaming_beam_hypotheses, None, None
+
+    def streaming_beam_search(self, audios: torch.Tensor, audio_lens: torch.Tensor, beam_size: int = 4,
+                              chunk_size_ms: Optional[int] = None) -> Tuple[List[List[int]], None, None]:
+        assert self.streaming, "Model is not in streaming mode for streaming_beam_search."
+        assert audios.size(0) == 1, "Streaming beam search currently supports batch size 1 only."
+        self.reset_streaming_cache()
+        n = int(audio_lens.item())
+        plan = self._utterance_chunks(n, chunk_size_ms)
+        if plan is None:
+            print(f"Error: Input audio too short ({n} frames) for conv layers. Skipping.")
+            return [[] for _ in range(audios.size(0))], None, None
+        for s, e, off in plan:
+            self.streaming_beam_hypotheses = self._decode_chunk_beam_search(audios[:, s:e, :], off, off, self.streaming_beam_hypotheses, beam_size)
+        if self.streaming_beam_hypotheses:
+            return [max(self.streaming_beam_hypotheses, key=lambda h: h.log_prob).tokens], None, None     # :598-601
+        return [[]], None, None
+
     def forward(self, audios, audio_lens, texts=None, text_lens=None):
         if not self.streaming or texts is not None:
             raise NotImplementedError("training / offline forward is outside the accelerated path (SURVEY.md §8a: a4,a5 only)")
@@ -209,18 +304,45 @@ class StreamingBatch:
     is B=1): the chunk loop of online_rnnt_decode.py:81-117 / streaming_inference for a whole batch."""
 
     def __init__(self, state_dict, n_streams: int, vocab_size: int = 412, blank_id: int = 5, max_chunk_frames: int = 64,
-                 max_cache_frames: int = 512, max_enc_frames: int = 512, max_tokens: int = 4096, device: int = 0):
+                 max_cache_frames: int = 512, max_enc_frames: int = 512, max_tokens: int = 4096, device: int = 0, max_beam: int = 0):
         self.device = torch.device("cuda", device)
         self.n = n_streams
+        self.blank_id = blank_id
         self.engine = RnntEngine(max_streams=n_streams, max_chunk_frames=max_chunk_frames, max_cache_frames=max_cache_frames,
                                  max_enc_frames=max_enc_frames, max_tokens=max_tokens, vocab_size=vocab_size, blank_id=blank_id,
-                                 n_steps=10, device=device)
+                                 n_steps=10, device=device, max_beam=max_beam)
+        self.beams = None
         self.engine.load_state_dict(state_dict)
         self.offset = 0
 
     def reset(self):
         self.engine.reset(self.n, _stream_ptr())
         self.offset = 0
+        self.beams = None
+
+    def process_chunk_beam(self, chunks: torch.Tensor, beam_size: int = 4):
+        """process_single_chunk_beam_search semantics for every stream (online_rnnt_model.py:605-645)."""
+        assert chunks.size(0) == self.n and chunks.is_cuda and chunks.dtype == torch.float32 and chunks.is_contiguous()
+        if chunks.size(1) < 7:
+            return self.beams
+        s = _stream_ptr()
+        tq = self.engine.encoder_chunk(chunks.data_ptr(), chunks.size(1), self.offset, self.offset, s)
+        self.offset += chunks.size(1) // 4
+        if self.beams is None:
+            self.beams = [[BeamHypothesis([], 0.0)] for _ in range(self.n)]
+            # fresh streams: pool rows must be one zero-state row per stream -> rows 0..n-1 are zero after reset
+        for t in range(tq):
+            self.beams = beam_advance_frame(self.engine, t, self.beams, self.blank_id, beam_size, s)
+        self.engine.frames_discard(s)
+        return self.beams
+
+    def beam_script(self, audios: torch.Tensor, chunk_frames: int, beam_size: int = 4):
+        """Beam loop of online_rnnt_decode.py:123-178 over [B,T,80]; returns the final beams per stream."""
+        from .testing import chunk_plan
+        self.reset()
+        for (a, b) in chunk_plan(audios.size(1), chunk_frames):
+            self.process_chunk_beam(audios[:, a:b, :].contiguous(), beam_size)
+        return self.beams
 
     def process_chunk(self, chunks: torch.Tensor, decode: bool = True):
         """chunks [B,T,80] on the device; process_single_chunk semantics for every stream."""

@@ -51,6 +51,7 @@ typedef struct {
     int32_t blank_id;          /* 5                                                                */
     int32_t n_steps;           /* max symbols per encoder frame (online_rnnt_model.py:174) = 10    */
     int32_t device;            /* HIP device ordinal                                               */
+    int32_t max_beam;          /* largest beam size for rnnt_beam_frame (0 = beam search unused)   */
 } rnnt_config;
 
 /* -- lifetime ------------------------------------------------------------------------------ */
@@ -101,6 +102,29 @@ int rnnt_get_tokens(rnnt_ctx* ctx, int32_t* counts_host, int32_t* tokens_host, v
 
 /* drop decoded frames from the encoder-frame buffer (keeps undecoded ones). */
 int rnnt_frames_consume(rnnt_ctx* ctx, void* stream);
+
+/* -- beam search: device half of _decode_chunk_beam_search (model/online_rnnt_model.py:419-503) -- */
+/* One encoder frame, all live hypotheses ("rows") of all streams at once.  For every row the library runs the
+ * reference's greedy extension chain (<= n_steps evaluations: predictor step, joint, log_softmax, blank
+ * log-prob, top-beam_k non-blank, stop when blank >= max - 1e-6, else extend with the best non-blank) and
+ * keeps every intermediate LSTM state in a pool.  The caller (host) owns the hypothesis bookkeeping — token
+ * lists, Python-double scores, stable sort, first-wins de-dup (:505-518) — and then tells the library which
+ * pooled state each surviving hypothesis keeps.
+ *   frame_idx            index into the buffered encoder frames
+ *   row_stream_host[n]   stream of each row;  row_tok_host[n] predictor input token (last token or blank)
+ *   steps_host[n]        evaluations done per row
+ *   blank_lp_host [n][n_steps], top_lp_host / top_tok_host [n][n_steps][beam_k]
+ * Row r's state before evaluation s is pool slot (r, s); the state after consuming the input token of
+ * evaluation s is slot (r, s+1).  Synchronises. */
+int rnnt_beam_frame(rnnt_ctx* ctx, int32_t frame_idx, int32_t n_rows, const int32_t* row_stream_host,
+                    const int32_t* row_tok_host, int32_t beam_k, int32_t* steps_host, float* blank_lp_host,
+                    float* top_lp_host, int32_t* top_tok_host, void* stream);
+/* new row r takes pool slot (src_row_host[r], src_step_host[r]); rows are renumbered 0..n_new-1. */
+int rnnt_beam_select(rnnt_ctx* ctx, int32_t n_new, const int32_t* src_row_host, const int32_t* src_step_host, void* stream);
+/* current [h,c] of rows 0..n_rows-1: h_host, c_host [n_rows,256].  Synchronises. */
+int rnnt_beam_get_states(rnnt_ctx* ctx, int32_t n_rows, float* h_host, float* c_host, void* stream);
+/* drop all buffered encoder frames (beam path; the greedy path uses rnnt_frames_consume). */
+int rnnt_frames_discard(rnnt_ctx* ctx, void* stream);
 
 /* -- step API (WeNet export precedent, wenet/transducer/transducer.py:444-472) ---------------- */
 /* forward_predictor_step (wenet/transducer/predictor.py:185-210): tokens_dev int32 [rows],

@@ -21,15 +21,15 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"librnnt_hip.so does not export {s}"
     assert sorted(rlib.SIGNATURES) == syms, "ctypes SIGNATURES and include/rnnt_hip.h disagree"
-    assert lib.rnnt_abi_version() == 1
+    assert lib.rnnt_abi_version() == 2
 
 
 def test_config_struct_layout():
     import ctypes
-    assert ctypes.sizeof(rlib.RnntConfig) == 9 * 4
+    assert ctypes.sizeof(rlib.RnntConfig) == 10 * 4
     assert [f[0] for f in rlib.RnntConfig._fields_] == [
         "max_streams", "max_chunk_frames", "max_cache_frames", "max_enc_frames", "max_tokens", "vocab_size", "blank_id",
-        "n_steps", "device"]
+        "n_steps", "device", "max_beam"]
 
 
 def test_null_context_error_string():

@@ -146,6 +146,36 @@ def test_streaming_inference_matches_reference(name, models):
     assert tuple(m.streaming_att_cache.shape) == tuple(g["att_cache_shape"])
 
 
+@pytest.mark.parametrize("name", ["beam_ex6_c16_s0", "beam_syn0_c16_s1_f320", "beam_ex0_c32_s0"])
+def test_beam_search_matches_reference(name, models):
+    """process_single_chunk_beam_search through the facade: after every chunk the beam (token lists in order,
+    Python-double scores) equals the reference's (online_rnnt_model.py:389-522)."""
+    g = load_golden(f"{name}.npz")
+    chunk, beam = int(g["chunk"]), int(g["beam"])
+    m = models(int(g["seed"]), chunk)
+    x = stream_input(name[5:])[:, :int(g["frames"])]
+    m.reset_streaming_cache()
+    for ci, (a, b) in enumerate(T.chunk_plan(x.shape[1], chunk)):
+        hyps, _, _ = m.process_single_chunk_beam_search(x[:, a:b], torch.tensor([b - a]), beam_size=beam)
+        assert len(hyps) == int(g[f"c{ci}_n"]), ci
+        for hi, h in enumerate(hyps):
+            assert h.tokens == g[f"c{ci}_h{hi}_tokens"].tolist(), (ci, hi)
+            assert abs(h.log_prob - float(g[f"c{ci}_h{hi}_logp"])) < 2e-3, (ci, hi)
+    assert hyps[0].predictor_states[0].shape == (1, 1, 256)
+
+
+def test_batched_beam_equals_single_stream(np_state_dict):
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    g = load_golden("beam_ex6_c16_s0.npz")
+    x = ex_inputs()["ex6"]
+    xb = torch.cat([x, x, x], 0).cuda().contiguous()
+    sb = StreamingBatch(np_state_dict(0), 3, max_chunk_frames=32, max_cache_frames=64, max_enc_frames=16, max_beam=4)
+    beams = sb.beam_script(xb, 16, 4)
+    last = int(g["n_chunks"]) - 1
+    for b in range(3):
+        assert [h.tokens for h in beams[b]] == [g[f"c{last}_h{i}_tokens"].tolist() for i in range(int(g[f"c{last}_n"]))]
+
+
 def test_enc_out_full_trace(models):
     g = load_golden("stream_syn0_c16_s0.npz")
     from ctc_vr_amd.online_rnnt_model import StreamingBatch  # noqa: F401
