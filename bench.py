@@ -74,8 +74,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="streams per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="fbank frames per stream (10 ms each)")
     ap.add_argument("--chunk", type=int, default=16, help="fbank frames per chunk (online_rnnt_decode.py semantics)")
-    ap.add_argument("--mode", default="per_chunk", choices=["per_chunk", "deferred"],
-                    help="per_chunk: tokens returned to the host after every chunk; deferred: one decode after the last chunk")
+    ap.add_argument("--mode", default="per_chunk", choices=["per_chunk", "deferred", "pipelined"],
+                    help="per_chunk: tokens returned to the host after every chunk; deferred: one decode after the last chunk; "
+                         "pipelined: whole chunk plan in one rnnt_encoder_chunks call (wavefront over chunk x layer), one decode")
     ap.add_argument("--site", default="conv2", choices=sorted(TAGS), help="launch site timed for the roofline object")
     ap.add_argument("--cpu-streams", type=int, default=8, help="streams of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -111,7 +112,7 @@ def main():
     per_chunk = args.mode == "per_chunk"
 
     def step():
-        return sb.decode_script(x, args.chunk, per_chunk_decode=per_chunk)
+        return sb.decode_script(x, args.chunk, per_chunk_decode=per_chunk, pipelined=args.mode == "pipelined")
 
     toks = None
     for _ in range(args.warmup):
@@ -146,13 +147,14 @@ def main():
     roofline = None
     if site_launches > 0:
         avg_s = site_ms * 1e-3 / site_launches
+        site_s = site_ms * 1e-3           # summed duration of every timed launch of the site over the timed region
         hbm = args.site in ("attn", "dwconv")
         if hbm:
-            ach = by / n_per_step / avg_s / 1e9
+            ach = by * args.steps / site_s / 1e9
             roofline = {"bound": "hbm", "kernel": f"{args.site}", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
         else:
-            ach = fl / n_per_step / avg_s / 1e12
+            ach = fl * args.steps / site_s / 1e12
             roofline = {"bound": "mfma", "kernel": f"gemm32 @ {args.site}", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
         roofline["avg_launch_us"] = round(avg_s * 1e6, 2)

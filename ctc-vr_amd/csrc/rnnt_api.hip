@@ -72,6 +72,13 @@ struct rnnt_ctx {
     int cache_len = 0, kv_start = 0, conv_pos = 0;
     int frames_buffered = 0, frames_decoded = 0;
     int64_t launches = 0, greedy_steps = 0;
+    // wavefront (whole-utterance) path: per-chunk x rows, per-layer scratch, subsampling slabs, descriptor tables
+    float *wf_x = nullptr, *wf_h = nullptr, *wf_q = nullptr, *wf_a = nullptr, *wf_d = nullptr, *wf_y1 = nullptr, *wf_y2 = nullptr;
+    int wf_slab = 0;
+    int* wf_starts = nullptr;
+    size_t wf_starts_cap = 0;
+    GemmP* wf_gtab = nullptr; AttnP* wf_atab = nullptr; DwP* wf_dtab = nullptr; LnP* wf_ltab = nullptr;
+    size_t wf_gcap = 0, wf_acap = 0, wf_dcap = 0, wf_lcap = 0;
     // optional per-kernel-site timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_tag = -1;
     std::vector<hipEvent_t> prof_ev;
@@ -226,93 +233,143 @@ const HostTensor* find(rnnt_ctx* ctx, const std::string& name) {
     return it == ctx->host.end() ? nullptr : &it->second;
 }
 
-// the attention / conv / FFN part of one Conformer block over rows [M = B*tq] of ctx->x
-// (ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:188-265).
-int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv_row0, int pos_start, int ring_pos,
-              const int* klen_dev) {
+// ---- descriptors of one Conformer block over rows [M = B*tq] of `x` ------------------------------------
+// (ConformerEncoderLayer.forward, wenet/transformer/encoder_layer.py:188-265).  Shared by the eager per-chunk
+// path (descriptors passed by value) and the wavefront path (descriptor tables in device memory).
+struct LayerDescs {
+    GemmP ffn1m, ffn2m, qkv[3], out, pw1, pw2, ffn1, ffn2;
+    AttnP attn;
+    DwP dw;
+    LnP lnf;
+};
+struct LayerBufs { float *x, *hbuf, *qbuf, *abuf, *dbuf; };
+
+int build_layer(rnnt_ctx* ctx, int l, int B, int tq, int T2, int kv_row0, int pos_start, int ring_pos, const int* klen_dev,
+                const LayerBufs& bf, LayerDescs& d) {
     const LayerW& w = ctx->lw[l];
     const int M = B * tq;
-    int rc;
+    float* kc = ctx->kcache + (size_t)l * ctx->cfg.max_streams * ctx->tcap * D;
+    float* vc = ctx->vcache + (size_t)l * ctx->cfg.max_streams * ctx->tcap * D;
+    float* gr = ctx->gring + (size_t)l * ctx->cfg.max_streams * ctx->cap * D;
+    float* xr = ctx->xring + (size_t)l * ctx->cfg.max_streams * ctx->cap * D;
     // x += 0.5 * FFN_macaron(LN(x))
-    {
-        GemmP g1 = plain_gemm(ctx->x, D, w.w1m, D, w.b1m, ctx->hbuf, FF, M, FF, D, EPI_SILU);
-        g1.ln_g = w.ln_ffm_g; g1.ln_b = w.ln_ffm_b;
-        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_FFN1))) return rc;
-        GemmP g2 = plain_gemm(ctx->hbuf, FF, w.w2m, FF, w.b2m, ctx->x, D, M, D, FF, EPI_RESID, 0.5f);
-        g2.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_FFN2))) return rc;
+    d.ffn1m = plain_gemm(bf.x, D, w.w1m, D, w.b1m, bf.hbuf, FF, M, FF, D, EPI_SILU);
+    d.ffn1m.ln_g = w.ln_ffm_g; d.ffn1m.ln_b = w.ln_ffm_b;
+    d.ffn2m = plain_gemm(bf.hbuf, FF, w.w2m, FF, w.b2m, bf.x, D, M, D, FF, EPI_RESID, 0.5f);
+    d.ffn2m.R = bf.x;
+    // x += linear_out(attention(LN(x))): q to a buffer, the new K/V rows appended behind the cached ones
+    d.qkv[0] = plain_gemm(bf.x, D, w.wq, D, w.bq, bf.qbuf, D, M, D, D);
+    d.qkv[1] = plain_gemm(bf.x, D, w.wk, D, w.bk, kc, D, M, D, D);
+    d.qkv[2] = plain_gemm(bf.x, D, w.wv, D, w.bv, vc, D, M, D, D);
+    for (int i = 0; i < 3; ++i) { d.qkv[i].ln_g = w.ln_mha_g; d.qkv[i].ln_b = w.ln_mha_b; }
+    for (int i = 1; i < 3; ++i) {
+        d.qkv[i].c_n = tq; d.qkv[i].c_s0 = (long long)ctx->tcap * D; d.qkv[i].c_r0 = kv_row0 + (T2 - tq); d.qkv[i].c_mod = BIG; d.qkv[i].c_s1 = D;
     }
-    // x += linear_out(attention(LN(x)))
-    {
-        float* kc = ctx->kcache + (size_t)l * ctx->cfg.max_streams * ctx->tcap * D;
-        float* vc = ctx->vcache + (size_t)l * ctx->cfg.max_streams * ctx->tcap * D;
-        GemmP g[3];
-        g[0] = plain_gemm(ctx->x, D, w.wq, D, w.bq, ctx->qbuf, D, M, D, D);
-        g[1] = plain_gemm(ctx->x, D, w.wk, D, w.bk, kc, D, M, D, D);
-        g[2] = plain_gemm(ctx->x, D, w.wv, D, w.bv, vc, D, M, D, D);
-        for (int i = 0; i < 3; ++i) { g[i].ln_g = w.ln_mha_g; g[i].ln_b = w.ln_mha_b; }
-        for (int i = 1; i < 3; ++i) {   // append the new K/V rows behind the cached ones
-            g[i].c_n = tq; g[i].c_s0 = (long long)ctx->tcap * D; g[i].c_r0 = kv_row0 + (T2 - tq); g[i].c_mod = BIG; g[i].c_s1 = D;
-        }
-        if ((rc = launch_gemm(ctx, s, 0, g, 3, TAG_QKV))) return rc;
-        dim3 grid(B * RNNT_H, (tq + ATT_QB - 1) / ATT_QB);
-        ProfScope prof(ctx, s, TAG_ATTN);
-        hipLaunchKernelGGL(rel_attention, grid, dim3(256), 0, s, ctx->qbuf, kc, vc, w.ptab, w.pu, w.pv, klen_dev, ctx->abuf, tq, T2,
-                           (long long)ctx->tcap, kv_row0, pos_start);
-        LAUNCHCHK("rel_attention");
-        GemmP go = plain_gemm(ctx->abuf, D, w.wo, D, w.bo, ctx->x, D, M, D, D, EPI_RESID, 1.0f);
-        go.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 0, &go, 1, TAG_ATTN_OUT))) return rc;
-    }
+    d.attn = AttnP{bf.qbuf, kc, vc, w.ptab, w.pu, w.pv, klen_dev, bf.abuf, tq, T2, kv_row0, pos_start, (long long)ctx->tcap};
+    d.out = plain_gemm(bf.abuf, D, w.wo, D, w.bo, bf.x, D, M, D, D, EPI_RESID, 1.0f);
+    d.out.R = bf.x;
     // x += conv_module(LN(x))
-    {
-        float* gr = ctx->gring + (size_t)l * ctx->cfg.max_streams * ctx->cap * D;
-        float* xr = ctx->xring + (size_t)l * ctx->cfg.max_streams * ctx->cap * D;
-        GemmP g1 = plain_gemm(ctx->x, D, w.pw1, D, w.bpw1, gr, D, M, 2 * D, D, EPI_GLU);
-        g1.ln_g = w.ln_conv_g; g1.ln_b = w.ln_conv_b;
-        g1.c_n = tq; g1.c_s0 = (long long)ctx->cap * D; g1.c_r0 = ring_pos % ctx->cap; g1.c_mod = ctx->cap; g1.c_s1 = D;
-        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_PW1))) return rc;
-        { ProfScope prof(ctx, s, TAG_DWCONV);
-        hipLaunchKernelGGL(dwconv_bn_silu, dim3(grid_for((long long)M * D)), dim3(256), 0, s, gr, w.wdw_t, w.bdw, w.bn_s, w.bn_t,
-                           ctx->dbuf, B, tq, ctx->cap, ring_pos, ctx->x, xr); }
-        LAUNCHCHK("dwconv_bn_silu");
-        GemmP g2 = plain_gemm(ctx->dbuf, D, w.pw2, D, w.bpw2, ctx->x, D, M, D, D, EPI_RESID, 1.0f);
-        g2.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_PW2))) return rc;
-    }
+    d.pw1 = plain_gemm(bf.x, D, w.pw1, D, w.bpw1, gr, D, M, 2 * D, D, EPI_GLU);
+    d.pw1.ln_g = w.ln_conv_g; d.pw1.ln_b = w.ln_conv_b;
+    d.pw1.c_n = tq; d.pw1.c_s0 = (long long)ctx->cap * D; d.pw1.c_r0 = ring_pos % ctx->cap; d.pw1.c_mod = ctx->cap; d.pw1.c_s1 = D;
+    d.dw = DwP{gr, w.wdw_t, w.bdw, w.bn_s, w.bn_t, bf.dbuf, bf.x, xr, B, tq, ctx->cap, ring_pos};
+    d.pw2 = plain_gemm(bf.dbuf, D, w.pw2, D, w.bpw2, bf.x, D, M, D, D, EPI_RESID, 1.0f);
+    d.pw2.R = bf.x;
     // x += 0.5 * FFN(LN(x)); x = LN_final(x)
-    {
-        GemmP g1 = plain_gemm(ctx->x, D, w.w1, D, w.b1, ctx->hbuf, FF, M, FF, D, EPI_SILU);
-        g1.ln_g = w.ln_ff_g; g1.ln_b = w.ln_ff_b;
-        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_FFN1))) return rc;
-        GemmP g2 = plain_gemm(ctx->hbuf, FF, w.w2, FF, w.b2, ctx->x, D, M, D, FF, EPI_RESID, 0.5f);
-        g2.R = ctx->x;
-        if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_FFN2))) return rc;
-        hipLaunchKernelGGL(layer_norm, dim3((M + 3) / 4), dim3(256), 0, s, ctx->x, w.ln_fin_g, w.ln_fin_b, ctx->x, M, BIG, 0LL, 0,
-                           (long long)D);
-        LAUNCHCHK("layer_norm");
-    }
+    d.ffn1 = plain_gemm(bf.x, D, w.w1, D, w.b1, bf.hbuf, FF, M, FF, D, EPI_SILU);
+    d.ffn1.ln_g = w.ln_ff_g; d.ffn1.ln_b = w.ln_ff_b;
+    d.ffn2 = plain_gemm(bf.hbuf, FF, w.w2, FF, w.b2, bf.x, D, M, D, FF, EPI_RESID, 0.5f);
+    d.ffn2.R = bf.x;
+    d.lnf = LnP{bf.x, w.ln_fin_g, w.ln_fin_b, bf.x, M, BIG, 0, 0LL, (long long)D};
     return RNNT_OK;
 }
 
-// Conv2dSubsampling4 (+ x16) of fbank [B,T,80] into ctx->x rows [B*t'] (subsampling.py:203-228).
-int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T) {
+int launch_attn(rnnt_ctx* ctx, hipStream_t s, const AttnP& a, int B) {
+    ProfScope prof(ctx, s, TAG_ATTN);
+    dim3 grid(B * RNNT_H, (a.tq + ATT_QB - 1) / ATT_QB);
+    hipLaunchKernelGGL(rel_attention, grid, dim3(256), 0, s, a);
+    LAUNCHCHK("rel_attention");
+    return RNNT_OK;
+}
+int launch_dw(rnnt_ctx* ctx, hipStream_t s, const DwP& d) {
+    ProfScope prof(ctx, s, TAG_DWCONV);
+    hipLaunchKernelGGL(dwconv_bn_silu, dim3(grid_for((long long)d.B * d.tq * D)), dim3(256), 0, s, d);
+    LAUNCHCHK("dwconv_bn_silu");
+    return RNNT_OK;
+}
+int launch_ln(rnnt_ctx* ctx, hipStream_t s, const LnP& p) {
+    hipLaunchKernelGGL(layer_norm, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    LAUNCHCHK("layer_norm");
+    return RNNT_OK;
+}
+
+int run_layer(rnnt_ctx* ctx, hipStream_t s, int l, int B, int tq, int T2, int kv_row0, int pos_start, int ring_pos,
+              const int* klen_dev) {
+    LayerDescs d;
+    LayerBufs bf{ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf};
+    int rc = build_layer(ctx, l, B, tq, T2, kv_row0, pos_start, ring_pos, klen_dev, bf, d);
+    if (rc) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.ffn1m, 1, TAG_FFN1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.ffn2m, 1, TAG_FFN2))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, d.qkv, 3, TAG_QKV))) return rc;
+    if ((rc = launch_attn(ctx, s, d.attn, B))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.out, 1, TAG_ATTN_OUT))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.pw1, 1, TAG_PW1))) return rc;
+    if ((rc = launch_dw(ctx, s, d.dw))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.pw2, 1, TAG_PW2))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.ffn1, 1, TAG_FFN1))) return rc;
+    if ((rc = launch_gemm(ctx, s, 0, &d.ffn2, 1, TAG_FFN2))) return rc;
+    return launch_ln(ctx, s, d.lnf);
+}
+
+// Conv2dSubsampling4 (+ x16) (subsampling.py:203-228) of `nc` equal-length chunks of every stream at once:
+// virtual stream v = c*B + b; output rows (v, r) -> xout[(v*tq + r)][256].  starts_dev == null: one chunk at 0.
+int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int Tstride, int T, const int* starts_dev, int nc,
+                  float* y1, float* y2, float* xout) {
     const int t1 = sub1_len(T), tq = sub_len(T);
+    const int VB = nc * B;
     int rc;
     { ProfScope prof(ctx, s, TAG_CONV1);
-    hipLaunchKernelGGL(conv1_relu, dim3(grid_for((long long)B * t1 * RNNT_F1 * D)), dim3(256), 0, s, fbank, ctx->conv1_wt, ctx->conv1_b,
-                       ctx->y1, B, T, t1); }
+    hipLaunchKernelGGL(conv1_relu, dim3(grid_for((long long)VB * t1 * RNNT_F1 * D)), dim3(256), 0, s, fbank, ctx->conv1_wt, ctx->conv1_b,
+                       y1, B, Tstride, t1, starts_dev, nc); }
     LAUNCHCHK("conv1_relu");
-    // conv2 as implicit GEMM: rows (b,t',f), K = (kh, kw, ci) = 3 segments of 768 contiguous floats of y1
-    GemmP g = plain_gemm(ctx->y1, 0, ctx->conv2_w, 2304, ctx->conv2_b, ctx->y2, D, B * tq * RNNT_FSUB, D, 2304, EPI_RELU);
+    // conv2 as implicit GEMM: rows (v,t',f), K = (kh, kw, ci) = 3 segments of 768 contiguous floats of y1
+    GemmP g = plain_gemm(y1, 0, ctx->conv2_w, 2304, ctx->conv2_b, y2, D, VB * tq * RNNT_FSUB, D, 2304, EPI_RELU);
     g.a_n1 = tq * RNNT_FSUB; g.a_n2 = RNNT_FSUB;
     g.a_s0 = (long long)t1 * RNNT_F1 * D; g.a_s1 = 2LL * RNNT_F1 * D; g.a_s2 = 2LL * D;
     g.a_seg = 768; g.a_seg_stride = (long long)RNNT_F1 * D;
     if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;
-    // Linear(4864 -> 256) * sqrt(256); y2 is [B*t', f*256 + c] (weight columns permuted to match)
-    GemmP go = plain_gemm(ctx->y2, RNNT_FSUB * D, ctx->emb_w, RNNT_FSUB * D, ctx->emb_b, ctx->x, D, B * tq, D, RNNT_FSUB * D, EPI_SCALE, 16.0f);
+    // Linear(4864 -> 256) * sqrt(256); y2 is [VB*t', f*256 + c] (weight columns permuted to match)
+    GemmP go = plain_gemm(y2, RNNT_FSUB * D, ctx->emb_w, RNNT_FSUB * D, ctx->emb_b, xout, D, VB * tq, D, RNNT_FSUB * D, EPI_SCALE, 16.0f);
     if ((rc = launch_gemm(ctx, s, 0, &go, 1, TAG_EMBED))) return rc;
     return RNNT_OK;
+}
+
+template <int WK, int NT>
+void launch_gemm16_tab(hipStream_t s, const GemmP* tab, int n, int maxM, int maxN) {
+    dim3 grid((maxN + 16 * NT - 1) / (16 * NT), (maxM + 15) / 16, n);
+    hipLaunchKernelGGL((gemm16_tab<WK, NT>), grid, dim3(64 * WK), 0, s, tab);
+}
+// n descriptors of one shape class (same N, K) in device memory
+int launch_gemm_tab(rnnt_ctx* ctx, hipStream_t s, const GemmP* tab_dev, int n, int maxM, int N, int K, int tag) {
+    ProfScope prof(ctx, s, tag);
+    const bool wide = N >= 512;
+    const int wk = K >= 1024 ? 8 : 4;
+    if (K % (wk * 16) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm16 K=%d not divisible by %d", K, wk * 16);
+    if (wide) { if (wk == 8) launch_gemm16_tab<8, 2>(s, tab_dev, n, maxM, N); else launch_gemm16_tab<4, 2>(s, tab_dev, n, maxM, N); }
+    else { if (wk == 8) launch_gemm16_tab<8, 1>(s, tab_dev, n, maxM, N); else launch_gemm16_tab<4, 1>(s, tab_dev, n, maxM, N); }
+    LAUNCHCHK("gemm16_tab");
+    return RNNT_OK;
+}
+
+template <typename T>
+int grow(rnnt_ctx* ctx, T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return RNNT_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    int rc = dmalloc(ctx, p, need);
+    *cap = rc ? 0 : need;
+    return rc;
 }
 
 }  // namespace
@@ -393,6 +450,10 @@ void rnnt_destroy(rnnt_ctx* ctx) {
         if (ctx->lw[l].ptab) (void)hipFree(ctx->lw[l].ptab);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    void* wf[] = {ctx->wf_x, ctx->wf_h, ctx->wf_q, ctx->wf_a, ctx->wf_d, ctx->wf_y1, ctx->wf_y2, ctx->wf_starts, ctx->wf_gtab, ctx->wf_atab,
+                  ctx->wf_dtab, ctx->wf_ltab};
+    for (void* q : wf)
+        if (q) (void)hipFree(q);
     delete ctx;
 }
 
@@ -635,13 +696,12 @@ int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t T, int32_t
     if (ctx->kv_start + T2 > ctx->tcap) return fail(ctx, RNNT_ERR_SHAPE, "K/V cache capacity %d exceeded", ctx->tcap);
     if (ctx->frames_buffered + tq > ctx->fcap) return fail(ctx, RNNT_ERR_SHAPE, "encoder-frame buffer capacity %d exceeded", ctx->fcap);
     int rc;
-    if ((rc = run_subsample(ctx, s, fbank_dev, B, T))) return rc;
+    if ((rc = run_subsample(ctx, s, fbank_dev, B, T, T, nullptr, 1, ctx->y1, ctx->y2, ctx->x))) return rc;
     for (int l = 0; l < L; ++l)
         if ((rc = run_layer(ctx, s, l, B, tq, T2, ctx->kv_start, pos_start, ctx->conv_pos, nullptr))) return rc;
     // after_norm straight into the frame buffer, then the joint's encoder projection for the new frames
-    hipLaunchKernelGGL(layer_norm, dim3((B * tq + 3) / 4), dim3(256), 0, s, ctx->x, ctx->after_g, ctx->after_b, ctx->encbuf, B * tq, tq,
-                       (long long)ctx->fstride * D, ctx->frames_buffered, (long long)D);
-    LAUNCHCHK("layer_norm");
+    if ((rc = launch_ln(ctx, s, LnP{ctx->x, ctx->after_g, ctx->after_b, ctx->encbuf, B * tq, tq, ctx->frames_buffered,
+                                    (long long)ctx->fstride * D, (long long)D}))) return rc;
     {
         GemmP g = plain_gemm(ctx->encbuf + (size_t)ctx->frames_buffered * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * tq, D, D);
         g.a_n1 = tq; g.a_n2 = tq; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
@@ -659,6 +719,172 @@ int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t T, int32_t
     ctx->conv_pos += tq;
     ctx->frames_buffered += tq;
     if (frames_out) *frames_out = tq;
+    return RNNT_OK;
+}
+
+// Whole-utterance encoder: every chunk of every stream, same results as n_chunks calls of rnnt_encoder_chunk.
+// (a) subsampling batched over runs of equal-length chunks; (b) WAVEFRONT over (chunk c, layer l): stage s runs
+// all pairs with c + l = s as ONE grouped launch per kernel type (layer l of chunk c needs only layer l-1 of
+// chunk c and layer l's K/V + conv caches after chunk c-1), so the dependent-launch chain is
+// (n_chunks + 11) stages instead of 12 * n_chunks; (c) after_norm + joint.enc_ffn for all new frames at once.
+int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_frames, int32_t n_chunks, const int32_t* chunk_start,
+                        const int32_t* chunk_len, const int32_t* offsets, const int32_t* required, int32_t* frames_out, void* stream) {
+    if (!ctx || !fbank_dev || !chunk_start || !chunk_len || !offsets || !required || n_chunks < 1)
+        return fail(ctx, RNNT_ERR_ARG, "rnnt_encoder_chunks: bad argument");
+    if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_encoder_chunks: no weights / no streams");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = ctx->n_streams, C = n_chunks;
+    const int Mmax = ctx->cfg.max_streams * ctx->tmax;
+    int rc;
+    // ---- static schedule: simulate the reference's per-chunk bookkeeping (encoder.py:254-264) -------------
+    struct CI { int len, tq, T2, kv_row0, pos_start, ring_pos, fpos; size_t xoff; };
+    std::vector<CI> ci(C);
+    int cache_len = ctx->cache_len, kv_start = ctx->kv_start, conv_pos = ctx->conv_pos, fb = ctx->frames_buffered;
+    size_t xrows = 0;
+    for (int c = 0; c < C; ++c) {
+        CI& k = ci[c];
+        k.len = chunk_len[c];
+        if (k.len < 7 || k.len > ctx->cfg.max_chunk_frames || chunk_start[c] < 0 || chunk_start[c] + k.len > total_frames)
+            return fail(ctx, RNNT_ERR_SHAPE, "chunk %d [%d,+%d) invalid for %d frames / max_chunk_frames %d", c, chunk_start[c], k.len,
+                        total_frames, ctx->cfg.max_chunk_frames);
+        k.tq = sub_len(k.len);
+        k.T2 = cache_len + k.tq;
+        k.pos_start = offsets[c] - cache_len;
+        k.kv_row0 = kv_start;
+        k.ring_pos = conv_pos;
+        k.fpos = fb;
+        k.xoff = xrows;
+        if (k.pos_start < 0 || k.pos_start + k.T2 > RNNT_PE_LEN) return fail(ctx, RNNT_ERR_SHAPE, "chunk %d: positional window outside the table", c);
+        if (kv_start + k.T2 > ctx->tcap) return fail(ctx, RNNT_ERR_SHAPE, "K/V cache capacity %d exceeded", ctx->tcap);
+        if (fb + k.tq > ctx->fcap) return fail(ctx, RNNT_ERR_SHAPE, "encoder-frame buffer capacity %d exceeded", ctx->fcap);
+        int next_start;
+        if (required[c] < 0) next_start = 0;
+        else if (required[c] == 0) next_start = k.T2;
+        else next_start = k.T2 - required[c] > 0 ? k.T2 - required[c] : 0;
+        kv_start += next_start;
+        cache_len = k.T2 - next_start;
+        if (cache_len == 0) kv_start = 0;
+        conv_pos += k.tq;
+        fb += k.tq;
+        xrows += (size_t)B * k.tq;
+    }
+    // ---- buffers ------------------------------------------------------------------------------------------------
+    if (!ctx->wf_x) {
+        const size_t Bm = ctx->cfg.max_streams;
+        size_t per_chunk = Bm * ctx->t1max * RNNT_F1 * D * sizeof(float);
+        ctx->wf_slab = (int)((192ull << 20) / per_chunk);
+        if (ctx->wf_slab < 1) ctx->wf_slab = 1;
+        if (ctx->wf_slab > 16) ctx->wf_slab = 16;
+        if ((rc = dmalloc(ctx, &ctx->wf_x, Bm * ctx->fcap * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_h, (size_t)L * Mmax * FF))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_q, (size_t)L * Mmax * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_a, (size_t)L * Mmax * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_d, (size_t)L * Mmax * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_y1, (size_t)ctx->wf_slab * Bm * ctx->t1max * RNNT_F1 * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_y2, (size_t)ctx->wf_slab * Mmax * RNNT_FSUB * D))) return rc;
+    }
+    if ((rc = grow(ctx, &ctx->wf_starts, &ctx->wf_starts_cap, (size_t)C))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->wf_starts, chunk_start, C * sizeof(int), hipMemcpyHostToDevice, s));
+    // ---- (a) subsampling, runs of equal-length chunks in slabs ------------------------------------------
+    for (int c0 = 0; c0 < C;) {
+        int c1 = c0 + 1;
+        while (c1 < C && ci[c1].len == ci[c0].len && c1 - c0 < ctx->wf_slab) ++c1;
+        if ((rc = run_subsample(ctx, s, fbank_dev, B, total_frames, ci[c0].len, ctx->wf_starts + c0, c1 - c0, ctx->wf_y1, ctx->wf_y2,
+                                ctx->wf_x + ci[c0].xoff * D)))
+            return rc;
+        c0 = c1;
+    }
+    // ---- (b) wavefront tables ---------------------------------------------------------------------------------
+    struct Launch { int type, off, n, maxM; };   // type 0..9 gemm (ffn1m ffn2m qkv out pw1 pw2 ffn1 ffn2), 10 attn, 11 dw, 12 ln
+    std::vector<GemmP> gt; std::vector<AttnP> at; std::vector<DwP> dt; std::vector<LnP> lt;
+    std::vector<Launch> seq;
+    gt.reserve((size_t)C * L * 12); at.reserve((size_t)C * L); dt.reserve((size_t)C * L); lt.reserve((size_t)C * (L + 1));
+    std::vector<LayerDescs> cur;
+    for (int st = 0; st < C + L - 1; ++st) {
+        cur.clear();
+        int maxM = 0, maxtq = 0;
+        for (int l = 0; l < L; ++l) {
+            const int c = st - l;
+            if (c < 0 || c >= C) continue;
+            LayerDescs d;
+            LayerBufs bf{ctx->wf_x + ci[c].xoff * D, ctx->wf_h + (size_t)l * Mmax * FF, ctx->wf_q + (size_t)l * Mmax * D,
+                         ctx->wf_a + (size_t)l * Mmax * D, ctx->wf_d + (size_t)l * Mmax * D};
+            if ((rc = build_layer(ctx, l, B, ci[c].tq, ci[c].T2, ci[c].kv_row0, ci[c].pos_start, ci[c].ring_pos, nullptr, bf, d))) return rc;
+            cur.push_back(d);
+            if (B * ci[c].tq > maxM) maxM = B * ci[c].tq;
+            if (ci[c].tq > maxtq) maxtq = ci[c].tq;
+        }
+        const int n = (int)cur.size();
+        auto add_g = [&](int type, GemmP LayerDescs::*f) -> int {
+            seq.push_back({type, (int)gt.size(), n, maxM});
+            for (auto& d : cur) { GemmP g = d.*f; int r2 = prepare_gemm(ctx, g); if (r2) return r2; gt.push_back(g); }
+            return 0;
+        };
+        if ((rc = add_g(0, &LayerDescs::ffn1m))) return rc;
+        if ((rc = add_g(1, &LayerDescs::ffn2m))) return rc;
+        seq.push_back({2, (int)gt.size(), 3 * n, maxM});
+        for (auto& d : cur)
+            for (int i = 0; i < 3; ++i) { GemmP g = d.qkv[i]; if ((rc = prepare_gemm(ctx, g))) return rc; gt.push_back(g); }
+        seq.push_back({10, (int)at.size(), n, maxtq});
+        for (auto& d : cur) at.push_back(d.attn);
+        if ((rc = add_g(3, &LayerDescs::out))) return rc;
+        if ((rc = add_g(4, &LayerDescs::pw1))) return rc;
+        seq.push_back({11, (int)dt.size(), n, maxM});
+        for (auto& d : cur) dt.push_back(d.dw);
+        if ((rc = add_g(5, &LayerDescs::pw2))) return rc;
+        if ((rc = add_g(6, &LayerDescs::ffn1))) return rc;
+        if ((rc = add_g(7, &LayerDescs::ffn2))) return rc;
+        seq.push_back({12, (int)lt.size(), n, maxM});
+        for (auto& d : cur) lt.push_back(d.lnf);
+    }
+    // (c) after_norm of every chunk straight into the frame buffer
+    int maxMc = 0;
+    const int ln_after_off = (int)lt.size();
+    for (int c = 0; c < C; ++c) {
+        lt.push_back(LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
+                         (long long)ctx->fstride * D, (long long)D});
+        if (B * ci[c].tq > maxMc) maxMc = B * ci[c].tq;
+    }
+    if ((rc = grow(ctx, &ctx->wf_gtab, &ctx->wf_gcap, gt.size()))) return rc;
+    if ((rc = grow(ctx, &ctx->wf_atab, &ctx->wf_acap, at.size()))) return rc;
+    if ((rc = grow(ctx, &ctx->wf_dtab, &ctx->wf_dcap, dt.size()))) return rc;
+    if ((rc = grow(ctx, &ctx->wf_ltab, &ctx->wf_lcap, lt.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->wf_gtab, gt.data(), gt.size() * sizeof(GemmP), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->wf_atab, at.data(), at.size() * sizeof(AttnP), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->wf_dtab, dt.data(), dt.size() * sizeof(DwP), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->wf_ltab, lt.data(), lt.size() * sizeof(LnP), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // the host vectors die at return; tables are small (a few MB)
+    static const int gN[8] = {FF, D, D, D, 2 * D, D, FF, D};
+    static const int gK[8] = {D, FF, D, D, D, D, D, FF};
+    static const int gTag[8] = {TAG_FFN1, TAG_FFN2, TAG_QKV, TAG_ATTN_OUT, TAG_PW1, TAG_PW2, TAG_FFN1, TAG_FFN2};
+    for (const Launch& q : seq) {
+        if (q.type < 8) {
+            if ((rc = launch_gemm_tab(ctx, s, ctx->wf_gtab + q.off, q.n, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
+        } else if (q.type == 10) {
+            ProfScope prof(ctx, s, TAG_ATTN);
+            dim3 grid(B * RNNT_H, (q.maxM + ATT_QB - 1) / ATT_QB, q.n);
+            hipLaunchKernelGGL(rel_attention_tab, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
+            LAUNCHCHK("rel_attention_tab");
+        } else if (q.type == 11) {
+            ProfScope prof(ctx, s, TAG_DWCONV);
+            hipLaunchKernelGGL(dwconv_bn_silu_tab, dim3(grid_for((long long)q.maxM * D), 1, q.n), dim3(256), 0, s, ctx->wf_dtab + q.off);
+            LAUNCHCHK("dwconv_bn_silu_tab");
+        } else {
+            hipLaunchKernelGGL(layer_norm_tab, dim3((q.maxM + 3) / 4, 1, q.n), dim3(256), 0, s, ctx->wf_ltab + q.off);
+            LAUNCHCHK("layer_norm_tab");
+        }
+    }
+    hipLaunchKernelGGL(layer_norm_tab, dim3((maxMc + 3) / 4, 1, C), dim3(256), 0, s, ctx->wf_ltab + ln_after_off);
+    LAUNCHCHK("layer_norm_tab");
+    {
+        const int F = fb - ctx->frames_buffered;   // new frames per stream
+        GemmP g = plain_gemm(ctx->encbuf + (size_t)ctx->frames_buffered * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * F, D, D);
+        g.a_n1 = F; g.a_n2 = F; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
+        g.c_n = F; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ctx->frames_buffered; g.c_mod = BIG; g.c_s1 = D;
+        if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
+        if (frames_out) *frames_out = F;
+    }
+    ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
     return RNNT_OK;
 }
 
@@ -886,12 +1112,10 @@ int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens
     const int saved = ctx->n_streams;
     ctx->n_streams = 0;   // streaming state invalid after a full-context pass
     (void)saved;
-    if ((rc = run_subsample(ctx, s, fbank_dev, B, T))) return rc;
+    if ((rc = run_subsample(ctx, s, fbank_dev, B, T, T, nullptr, 1, ctx->y1, ctx->y2, ctx->x))) return rc;
     for (int l = 0; l < L; ++l)
         if ((rc = run_layer(ctx, s, l, B, tq, tq, 0, 0, 0, ctx->klen))) return rc;
-    hipLaunchKernelGGL(layer_norm, dim3((B * tq + 3) / 4), dim3(256), 0, s, ctx->x, ctx->after_g, ctx->after_b, out_dev, B * tq, BIG, 0LL, 0,
-                       (long long)D);
-    LAUNCHCHK("layer_norm");
+    if ((rc = launch_ln(ctx, s, LnP{ctx->x, ctx->after_g, ctx->after_b, out_dev, B * tq, BIG, 0, 0LL, (long long)D}))) return rc;
     if (frames_out) *frames_out = tq;
     return RNNT_OK;
 }

@@ -310,10 +310,9 @@ __device__ __forceinline__ long long c_row_off(const GemmP& p, int m) {
 }
 
 template <int WK, int NT>
-__global__ __launch_bounds__(64 * WK) void gemm16(GemmBatch gb) {
+__device__ __forceinline__ void gemm16_body(const GemmP& p) {
     __shared__ __attribute__((aligned(16))) float part[WK * NT * 256];
     __shared__ float st[32];
-    const GemmP& p = gb.g[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * (16 * NT);
     if (m0 >= p.M || n0 >= p.N) return;
@@ -480,22 +479,37 @@ __global__ __launch_bounds__(64 * WK) void gemm16(GemmBatch gb) {
     }
 }
 
+template <int WK, int NT>
+__global__ __launch_bounds__(64 * WK) void gemm16(GemmBatch gb) {
+    gemm16_body<WK, NT>(gb.g[blockIdx.z]);
+}
+// table-driven variant: one descriptor per blockIdx.z in device memory (wavefront schedule: up to 36 groups)
+template <int WK, int NT>
+__global__ __launch_bounds__(64 * WK) void gemm16_tab(const GemmP* __restrict__ tab) {
+    gemm16_body<WK, NT>(tab[blockIdx.z]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv1_relu: y1[b][t][f][c] = relu(b1[c] + sum_{kh,kw} x[b][2t+kh][2f+kw] * w1[c][kh][kw])
 // (Conv2d(1,256,3,2)+ReLU, wenet/transformer/subsampling.py:189-190).  Channels-last so that the
 // conv2 implicit GEMM reads 768 contiguous floats per kernel row.  One thread per (b,t,f,c).
 // ------------------------------------------------------------------------------------------------
+// Virtual streams: v = c*B + b reads fbank[b][starts[c] .. ) (starts == null -> c = 0, start 0): the
+// wavefront path subsamples several equal-length chunks of every stream in one launch.
 __global__ void conv1_relu(const float* __restrict__ x, const float* __restrict__ w1t /*[9][256]*/,
-                           const float* __restrict__ b1, float* __restrict__ y1, int B, int T, int t1) {
-    const long long n = (long long)B * t1 * RNNT_F1 * RNNT_D;
+                           const float* __restrict__ b1, float* __restrict__ y1, int B, int T, int t1,
+                           const int* __restrict__ starts, int n_chunks) {
+    const long long n = (long long)n_chunks * B * t1 * RNNT_F1 * RNNT_D;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id & 255);
         long long r = id >> 8;
         const int f = (int)(r % RNNT_F1);
         r /= RNNT_F1;
         const int t = (int)(r % t1);
-        const int b = (int)(r / t1);
-        const float* xp = x + ((long long)b * T + 2 * t) * RNNT_IDIM + 2 * f;
+        const int v = (int)(r / t1);
+        const int cidx = v / B, b = v - cidx * B;
+        const int st0 = starts ? starts[cidx] : 0;
+        const float* xp = x + ((long long)b * T + st0 + 2 * t) * RNNT_IDIM + 2 * f;
         float acc = b1[c];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -508,27 +522,36 @@ __global__ void conv1_relu(const float* __restrict__ x, const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // layer_norm: y[row] = LN(x[row]) over 256 columns, one wave per row, output row map like gemm C.
 // ------------------------------------------------------------------------------------------------
-__global__ void layer_norm(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                           float* __restrict__ y, int M, int c_n, long long c_s0, int c_r0, long long c_s1) {
+struct LnP {
+    const float* x;
+    const float* g;
+    const float* b;
+    float* y;
+    int M, c_n, c_r0;
+    long long c_s0, c_s1;
+};
+__device__ __forceinline__ void layer_norm_body(const LnP& p) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= M) return;
-    const float4 v = *reinterpret_cast<const float4*>(x + (long long)row * RNNT_D + lane * 4);
+    if (row >= p.M) return;
+    const float4 v = *reinterpret_cast<const float4*>(p.x + (long long)row * RNNT_D + lane * 4);
     const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
     const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
     const float rstd = 1.0f / sqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
-    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
-    const float4 bb = *reinterpret_cast<const float4*>(b + lane * 4);
+    const float4 gg = *reinterpret_cast<const float4*>(p.g + lane * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(p.b + lane * 4);
     float4 o;
     o.x = dx * rstd * gg.x + bb.x;
     o.y = dy * rstd * gg.y + bb.y;
     o.z = dz * rstd * gg.z + bb.z;
     o.w = dw * rstd * gg.w + bb.w;
     long long off;
-    if (c_s0 == 0) off = (long long)(row + c_r0) * c_s1;   // plain rows
-    else off = (long long)(row / c_n) * c_s0 + (long long)((row % c_n) + c_r0) * c_s1;
-    *reinterpret_cast<float4*>(y + off + lane * 4) = o;
+    if (p.c_s0 == 0) off = (long long)(row + p.c_r0) * p.c_s1;   // plain rows
+    else off = (long long)(row / p.c_n) * p.c_s0 + (long long)((row % p.c_n) + p.c_r0) * p.c_s1;
+    *reinterpret_cast<float4*>(p.y + off + lane * 4) = o;
 }
+__global__ void layer_norm(LnP p) { layer_norm_body(p); }
+__global__ void layer_norm_tab(const LnP* __restrict__ tab) { layer_norm_body(tab[blockIdx.z]); }
 
 // ------------------------------------------------------------------------------------------------
 // rel_attention: RelPositionMultiHeadedAttention score/softmax/PV (attention.py:400-418,170-177)
@@ -544,11 +567,30 @@ __global__ void layer_norm(const float* __restrict__ x, const float* __restrict_
 #define ATT_QB 16
 #define ATT_TK 64
 #define ATT_LD 68
-__global__ __launch_bounds__(256) void rel_attention(const float* __restrict__ q, const float* __restrict__ kc,
-                                                    const float* __restrict__ vc, const float* __restrict__ ptab,
-                                                    const float* __restrict__ bias_u, const float* __restrict__ bias_v,
-                                                    const int* __restrict__ klen, float* __restrict__ out, int tq, int T2,
-                                                    long long kv_stride, int kv_start, int pos_start) {
+struct AttnP {
+    const float* q;
+    const float* kc;
+    const float* vc;
+    const float* ptab;
+    const float* bias_u;
+    const float* bias_v;
+    const int* klen;
+    float* out;
+    int tq, T2, kv_start, pos_start;
+    long long kv_stride;
+};
+__device__ __forceinline__ void rel_attention_body(const AttnP& P) {
+    const float* __restrict__ q = P.q;
+    const float* __restrict__ kc = P.kc;
+    const float* __restrict__ vc = P.vc;
+    const float* __restrict__ ptab = P.ptab;
+    const float* __restrict__ bias_u = P.bias_u;
+    const float* __restrict__ bias_v = P.bias_v;
+    const int* __restrict__ klen = P.klen;
+    float* __restrict__ out = P.out;
+    const int tq = P.tq, T2 = P.T2, kv_start = P.kv_start, pos_start = P.pos_start;
+    const long long kv_stride = P.kv_stride;
+    if ((int)blockIdx.y * ATT_QB >= tq) return;
     __shared__ __attribute__((aligned(16))) float Ks[ATT_TK * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Ps[ATT_TK * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_TK * RNNT_DK];
@@ -648,6 +690,8 @@ __global__ __launch_bounds__(256) void rel_attention(const float* __restrict__ q
         if (iq < nq) out[((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + lane] = o[sI] / lrun[sI];
     }
 }
+__global__ __launch_bounds__(256) void rel_attention(AttnP p) { rel_attention_body(p); }
+__global__ __launch_bounds__(256) void rel_attention_tab(const AttnP* __restrict__ tab) { rel_attention_body(tab[blockIdx.z]); }
 
 // ------------------------------------------------------------------------------------------------
 // dwconv_bn_silu: causal depthwise conv k=31 + BatchNorm(eval) + SiLU over the post-GLU ring
@@ -657,10 +701,27 @@ __global__ __launch_bounds__(256) void rel_attention(const float* __restrict__ q
 // pre-LayerNorm conv-module input rows into the xin ring (for the reference's cnn_cache view).
 //   out[m][c] = silu((bdw[c] + sum_k wdw[k][c] * g[frame pos+r-30+k][c]) * bn_s[c] + bn_t[c])
 // ------------------------------------------------------------------------------------------------
-__global__ void dwconv_bn_silu(const float* __restrict__ g, const float* __restrict__ wdw_t /*[31][256]*/,
-                               const float* __restrict__ bdw, const float* __restrict__ bn_s,
-                               const float* __restrict__ bn_t, float* __restrict__ out, int B, int tq, int cap, int pos,
-                               const float* __restrict__ xres, float* __restrict__ xring) {
+struct DwP {
+    const float* g;
+    const float* wdw_t;
+    const float* bdw;
+    const float* bn_s;
+    const float* bn_t;
+    float* out;
+    const float* xres;
+    float* xring;
+    int B, tq, cap, pos;
+};
+__device__ __forceinline__ void dwconv_body(const DwP& P) {
+    const float* __restrict__ g = P.g;
+    const float* __restrict__ wdw_t = P.wdw_t;
+    const float* __restrict__ bdw = P.bdw;
+    const float* __restrict__ bn_s = P.bn_s;
+    const float* __restrict__ bn_t = P.bn_t;
+    float* __restrict__ out = P.out;
+    const float* __restrict__ xres = P.xres;
+    float* __restrict__ xring = P.xring;
+    const int B = P.B, tq = P.tq, cap = P.cap, pos = P.pos;
     const long long n = (long long)B * tq * RNNT_D;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id & 255);
@@ -680,6 +741,8 @@ __global__ void dwconv_bn_silu(const float* __restrict__ g, const float* __restr
         if (xring) xring[((long long)b * cap + (pos + r) % cap) * RNNT_D + c] = xres[id];
     }
 }
+__global__ void dwconv_bn_silu(DwP p) { dwconv_body(p); }
+__global__ void dwconv_bn_silu_tab(const DwP* __restrict__ tab) { dwconv_body(tab[blockIdx.z]); }
 
 // fill the 30 left-context rows of a fresh stream: g ring <- GLU(b_pw1) (zero input through the
 // biased pointwise conv, convolution.py:122-124,138-139), xin ring <- 0.

@@ -356,13 +356,31 @@ class StreamingBatch:
             self.engine.greedy_decode(s)
             self.engine.frames_consume(s)
 
-    def decode_script(self, audios: torch.Tensor, chunk_frames: int, per_chunk_decode: bool = True) -> List[List[int]]:
+    def decode_script(self, audios: torch.Tensor, chunk_frames: int, per_chunk_decode: bool = True, pipelined: bool = False) -> List[List[int]]:
         """Greedy loop of online_rnnt_decode.py:81-117 over [B,T,80] equal-length utterances.
         per_chunk_decode=False runs the encoder over all chunks first and decodes once at the end
-        (identical tokens: the greedy state machine is causal in the frame index)."""
+        (identical tokens: the greedy state machine is causal in the frame index).
+        pipelined=True hands the whole chunk plan to rnnt_encoder_chunks (wavefront over chunk x layer,
+        bit-identical encoder output) and decodes once."""
         from .testing import chunk_plan
         self.reset()
         T = audios.size(1)
+        if pipelined:
+            assert audios.is_cuda and audios.dtype == torch.float32 and audios.is_contiguous()
+            plan = chunk_plan(T, chunk_frames)
+            starts = [a for a, b in plan if b - a >= 7]
+            lens = [b - a for a, b in plan if b - a >= 7]
+            offs, o = [], 0
+            for a, b in plan:                      # process_single_chunk: offset += frames // 4 (online_rnnt_model.py:384-385)
+                if b - a >= 7:
+                    offs.append(o)
+                    o += (b - a) // 4
+            s = _stream_ptr()
+            self.engine.encoder_chunks(audios.data_ptr(), T, starts, lens, offs, offs, s)
+            self.offset = o
+            self.engine.greedy_decode(s)
+            self.engine.frames_consume(s)
+            return self.engine.tokens(s)
         for (a, b) in chunk_plan(T, chunk_frames):
             self.process_chunk(audios[:, a:b, :].contiguous(), decode=per_chunk_decode)
         if not per_chunk_decode:

@@ -91,6 +91,15 @@ int rnnt_streams_reset(rnnt_ctx* ctx, int32_t n_streams, void* stream);
 int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t chunk_frames, int32_t offset,
                        int32_t required_cache_size, int32_t* frames_out, void* stream);
 
+/* replaces the whole chunk loop around forward_chunk (online_rnnt_decode.py:87-117, or streaming_inference,
+ * model/online_rnnt_model.py:311-342) for utterances that are fully available: chunk c of every stream covers fbank
+ * frames [chunk_start[c], chunk_start[c]+chunk_len[c]) and is encoded with (offsets[c], required[c]) exactly as
+ * n_chunks calls of rnnt_encoder_chunk would (bit-identical results), but scheduled as a wavefront over
+ * (chunk, layer) with batched subsampling.  fbank_dev [n_streams, total_frames, 80]; host int arrays. */
+int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_frames, int32_t n_chunks,
+                        const int32_t* chunk_start, const int32_t* chunk_len, const int32_t* offsets,
+                        const int32_t* required, int32_t* frames_out, void* stream);
+
 /* replaces the greedy loops of _decode_chunk_streaming_logic (model/online_rnnt_model.py:183-222)
  * over every buffered encoder frame not yet decoded, all streams in parallel, state carried in
  * the context (LSTM [h,c], last token).  Appends to the per-stream token buffers.  Synchronises. */

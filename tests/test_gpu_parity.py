@@ -209,6 +209,35 @@ def test_batched_streams_equal_single_stream_reference(np_state_dict):
             assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (per_chunk, i)
 
 
+def test_wavefront_encoder_is_bit_identical(np_state_dict):
+    """rnnt_encoder_chunks (wavefront over chunk x layer, batched subsampling) vs chunk-by-chunk
+    rnnt_encoder_chunk: encoder frames and K/V cache bit-identical, tokens equal the reference."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
+    syn = torch.from_numpy(T.synth_fbank(2, 1000))
+    x = torch.stack([syn[i % 2] for i in range(4)]).cuda().contiguous()
+    sb = StreamingBatch(np_state_dict(0), 4, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256)
+    s = torch.cuda.current_stream().cuda_stream
+    sb.reset()
+    for (a, b) in T.chunk_plan(1000, 16):
+        sb.process_chunk(x[:, a:b].contiguous(), decode=False)
+    enc_seq = sb.engine.enc_frames(s)
+    att_seq = sb.engine.att_cache(1, s)
+    cnn_seq = sb.engine.cnn_cache(1, s)
+    sb.engine.greedy_decode(s)
+    toks = sb.decode_script(x, 16, pipelined=True)
+    for i in range(4):
+        assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), i
+    sb.reset()
+    plan = T.chunk_plan(1000, 16)
+    offs = [4 * i for i in range(len(plan))]
+    sb.engine.encoder_chunks(x.data_ptr(), 1000, [a for a, _ in plan], [b - a for a, b in plan], offs, offs, s)
+    assert np.array_equal(sb.engine.enc_frames(s), enc_seq)
+    assert np.array_equal(sb.engine.att_cache(1, s), att_seq)
+    assert np.array_equal(sb.engine.cnn_cache(1, s), cnn_seq)
+    assert maxdiff(enc_seq[0], g0["enc_out"]) < LOGIT_TOL
+
+
 def test_fresh_inputs_against_oracle(np_state_dict):
     """Seeded inputs no fixture covers: HIP (B=4, chunk 24) vs the CPU oracle run stream by stream."""
     from oracle import rnnt_oracle as O
