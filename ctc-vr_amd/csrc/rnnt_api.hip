@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -56,8 +58,11 @@ struct rnnt_ctx {
     float *kcache = nullptr, *vcache = nullptr, *gring = nullptr, *xring = nullptr;
     float *encbuf = nullptr, *encp = nullptr;
     // decode state
-    float *h = nullptr, *c = nullptr, *h2 = nullptr, *c2 = nullptr, *pred = nullptr, *z = nullptr, *logits = nullptr;
-    int *tok = nullptr, *fidx = nullptr, *nsym = nullptr, *count = nullptr, *tokens = nullptr, *n_active = nullptr, *klen = nullptr;
+    // LSTM state: two buffers [2][B][256] per h and c; sel[b] says which one is committed, the other receives the candidate
+    float *h = nullptr, *c = nullptr, *pred = nullptr, *z = nullptr, *logits = nullptr;
+    int *tok = nullptr, *fidx = nullptr, *nsym = nullptr, *count = nullptr, *tokens = nullptr, *n_active = nullptr, *klen = nullptr, *sel = nullptr;
+    unsigned long long* key = nullptr;
+    const float *wjc = nullptr, *bjc = nullptr;   // folded joint.pred_ffn o predictor.projection
     // beam search: state pools [rows][n_steps+1][512] (ping-pong), per-row buffers
     int max_rows = 0;
     float *pool[2] = {nullptr, nullptr}, *bpred = nullptr, *bz = nullptr, *blogits = nullptr, *b_blank = nullptr, *b_toplp = nullptr;
@@ -79,6 +84,13 @@ struct rnnt_ctx {
     size_t wf_starts_cap = 0;
     GemmP* wf_gtab = nullptr; AttnP* wf_atab = nullptr; DwP* wf_dtab = nullptr; LnP* wf_ltab = nullptr;
     size_t wf_gcap = 0, wf_acap = 0, wf_dcap = 0, wf_lcap = 0;
+    hipStream_t dec_stream = nullptr;          // decode runs here while the encoder wavefront runs on the caller's stream
+    hipStream_t cap_stream = nullptr;          // stream-capture scratch stream
+    struct DecGraph { int n_streams, k; hipGraphExec_t exec; };
+    std::vector<DecGraph> dec_graphs;          // K greedy steps captured once per (n_streams, K)
+    bool capturing = false;
+    int use_graphs = 1;
+    std::vector<hipEvent_t> wf_ev;
     // optional per-kernel-site timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_tag = -1;
     std::vector<hipEvent_t> prof_ev;
@@ -117,7 +129,7 @@ enum { TAG_NONE = 0, TAG_CONV1 = 1, TAG_CONV2 = 2, TAG_EMBED = 3, TAG_FFN1 = 4, 
 
 struct ProfScope {   // records a start/stop event pair around one launch when its site is selected
     rnnt_ctx* ctx; hipStream_t s; bool on;
-    ProfScope(rnnt_ctx* c, hipStream_t st, int tag) : ctx(c), s(st), on(c->prof_tag == tag && tag != TAG_NONE) {
+    ProfScope(rnnt_ctx* c, hipStream_t st, int tag) : ctx(c), s(st), on(c->prof_tag == tag && tag != TAG_NONE && !c->capturing) {
         if (on) {
             if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
                 for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); ctx->prof_ev.push_back(e); }
@@ -177,7 +189,7 @@ int prepare_gemm(rnnt_ctx* ctx, GemmP& g) {
 template <int WK, int NT>
 void launch_gemm16(hipStream_t s, const GemmBatch& gb, int maxM, int maxN, int ng) {
     dim3 grid((maxN + 16 * NT - 1) / (16 * NT), (maxM + 15) / 16, ng);
-    hipLaunchKernelGGL((gemm16<WK, NT>), grid, dim3(64 * WK), 0, s, gb);
+    hipLaunchKernelGGL((gemm16<WK, 1, NT>), grid, dim3(64 * WK), 0, s, gb);
 }
 
 // wk > 0: gemm32 (32x32 tiles, large-M implicit-GEMM conv2); wk == 0: gemm16 with a shape heuristic
@@ -286,8 +298,11 @@ int build_layer(rnnt_ctx* ctx, int l, int B, int tq, int T2, int kv_row0, int po
 
 int launch_attn(rnnt_ctx* ctx, hipStream_t s, const AttnP& a, int B) {
     ProfScope prof(ctx, s, TAG_ATTN);
-    dim3 grid(B * RNNT_H, (a.tq + ATT_QB - 1) / ATT_QB);
-    hipLaunchKernelGGL(rel_attention, grid, dim3(256), 0, s, a);
+    const int nq = a.tq <= 4 ? 1 : (a.tq <= 8 ? 2 : 4);
+    dim3 grid(B * RNNT_H, (a.tq + 4 * nq - 1) / (4 * nq));
+    if (nq == 1) hipLaunchKernelGGL(rel_attention<1>, grid, dim3(256), 0, s, a);
+    else if (nq == 2) hipLaunchKernelGGL(rel_attention<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rel_attention<4>, grid, dim3(256), 0, s, a);
     LAUNCHCHK("rel_attention");
     return RNNT_OK;
 }
@@ -345,20 +360,127 @@ int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T
     return RNNT_OK;
 }
 
-template <int WK, int NT>
+template <int WK, int MT, int NT>
 void launch_gemm16_tab(hipStream_t s, const GemmP* tab, int n, int maxM, int maxN) {
-    dim3 grid((maxN + 16 * NT - 1) / (16 * NT), (maxM + 15) / 16, n);
-    hipLaunchKernelGGL((gemm16_tab<WK, NT>), grid, dim3(64 * WK), 0, s, tab);
+    dim3 grid((maxN + 16 * NT - 1) / (16 * NT), (maxM + 16 * MT - 1) / (16 * MT), n);
+    hipLaunchKernelGGL((gemm16_tab<WK, MT, NT>), grid, dim3(64 * WK), 0, s, tab);
 }
-// n descriptors of one shape class (same N, K) in device memory
+// n descriptors of one shape class (same N, K) in device memory.  Tile choice: with n >= 6 groups there are enough
+// workgroups to spend registers on operand reuse (64x64 / 32x64 tiles); few groups keep the 16-row tiles.
 int launch_gemm_tab(rnnt_ctx* ctx, hipStream_t s, const GemmP* tab_dev, int n, int maxM, int N, int K, int tag) {
     ProfScope prof(ctx, s, tag);
-    const bool wide = N >= 512;
+    static const int ns_mode = getenv("RNNT_GEMM_NS") ? atoi(getenv("RNNT_GEMM_NS")) : 1;
+    if (ns_mode && n >= 6 && K % 32 == 0) {   // enough groups: no split-K, epilogue from registers
+        const int ntn = (N + 63) / 64;
+        if (K >= 1024 || N <= 256) {          // 32x64 workgroup tiles (more workgroups for the narrow / deep shapes)
+            const int ntm = (maxM + 31) / 32;
+            hipLaunchKernelGGL((gemm_ns_tab<1, 2>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+        } else {                              // 64x64 workgroup tiles
+            const int ntm = (maxM + 63) / 64;
+            hipLaunchKernelGGL((gemm_ns_tab<2, 2>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+        }
+        LAUNCHCHK("gemm_ns_tab");
+        return RNNT_OK;
+    }
     const int wk = K >= 1024 ? 8 : 4;
     if (K % (wk * 16) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm16 K=%d not divisible by %d", K, wk * 16);
-    if (wide) { if (wk == 8) launch_gemm16_tab<8, 2>(s, tab_dev, n, maxM, N); else launch_gemm16_tab<4, 2>(s, tab_dev, n, maxM, N); }
-    else { if (wk == 8) launch_gemm16_tab<8, 1>(s, tab_dev, n, maxM, N); else launch_gemm16_tab<4, 1>(s, tab_dev, n, maxM, N); }
+    const long long out = (long long)n * maxM * N;
+    if (out >= 256ll * 64 * 64 * 2 && wk == 4) launch_gemm16_tab<4, 4, 4>(s, tab_dev, n, maxM, N);
+    else if (out >= 256ll * 32 * 64 && wk == 4) launch_gemm16_tab<4, 2, 4>(s, tab_dev, n, maxM, N);
+    else if (out >= 256ll * 32 * 64 && wk == 8) launch_gemm16_tab<8, 2, 4>(s, tab_dev, n, maxM, N);
+    else if (N >= 512) { if (wk == 8) launch_gemm16_tab<8, 1, 2>(s, tab_dev, n, maxM, N); else launch_gemm16_tab<4, 1, 2>(s, tab_dev, n, maxM, N); }
+    else { if (wk == 8) launch_gemm16_tab<8, 1, 1>(s, tab_dev, n, maxM, N); else launch_gemm16_tab<4, 1, 1>(s, tab_dev, n, maxM, N); }
     LAUNCHCHK("gemm16_tab");
+    return RNNT_OK;
+}
+
+// `n` lock-step greedy evaluations for all streams over the buffered frames (n_frames in device memory)
+// (_decode_chunk_streaming_logic inner loop, online_rnnt_model.py:196-220), 4 launches per evaluation:
+//   greedy_decide   apply the previous argmax to every stream's state machine (token / frame / state-buffer select)
+//   LSTM cell       gates = E[tok] + h * W_hh^T, candidate (h', c') into the non-committed buffer (predictor.py:200-204)
+//   joint tanh      z = tanh(enc_ffn(enc)[t_b] + (pred_ffn o projection)(h')) (joint.py:54-66, folded Linear pair)
+//   joint out       logits = z * W_out^T + b, argmax fused into the epilogue (packed atomicMax; online_rnnt_model.py:212)
+// Streams without frames idle.
+GreedyState greedy_state(rnnt_ctx* ctx) {
+    return GreedyState{ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->sel, ctx->key, ctx->n_active};
+}
+
+int greedy_steps_raw(rnnt_ctx* ctx, hipStream_t s, int n) {
+    const int B = ctx->n_streams, V = ctx->cfg.vocab_size;
+    const long long bs = (long long)ctx->cfg.max_streams * D;   // floats between the two state buffers
+    GreedyState st = greedy_state(ctx);
+    int rc;
+    for (int it = 0; it < n; ++it) {
+        hipLaunchKernelGGL(greedy_decide, dim3(1), dim3(64), 0, s, B, ctx->cfg.blank_id, ctx->cfg.n_steps, ctx->cfg.max_tokens, 0, st);
+        LAUNCHCHK("greedy_decide");
+        GemmP g1 = plain_gemm(ctx->h, D, ctx->whh_il, D, nullptr, ctx->h, D, B, 4 * D, D, EPI_LSTM);
+        g1.X = ctx->egate; g1.I = ctx->tok; g1.X2 = ctx->c; g1.Y2 = ctx->c;
+        g1.Asel = ctx->sel; g1.asel_stride = bs; g1.asel_invert = 0;
+        if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_LSTM))) return rc;
+        GemmP g3 = plain_gemm(ctx->h, D, ctx->wjc, D, ctx->bjc, ctx->z, D, B, D, D, EPI_TANH_ADD);
+        g3.Asel = ctx->sel; g3.asel_stride = bs; g3.asel_invert = 1;   // candidate h' lives in the other buffer
+        g3.X = ctx->encp; g3.I = ctx->fidx; g3.x_n = 1; g3.x_s0 = (long long)ctx->fstride * D; g3.x_s1 = D;
+        if ((rc = launch_gemm(ctx, s, 0, &g3, 1, TAG_JOINT_TANH))) return rc;
+        GemmP g4 = plain_gemm(ctx->z, D, ctx->wout, D, ctx->bout, ctx->logits, ctx->vpad, B, V, D, EPI_ARGMAX);
+        g4.key = ctx->key; g4.I = ctx->fidx; g4.nframes = ctx->n_active + 2;
+        if ((rc = launch_gemm(ctx, s, 0, &g4, 1, TAG_JOINT_OUT))) return rc;
+    }
+    return RNNT_OK;
+}
+
+// n greedy steps over the first n_frames buffered frames; the step sequence has static arguments, so it is captured
+// once per (n_streams, n) into a hipGraph and replayed with ONE host call (the path is launch-bound: 5 kernels/step).
+int greedy_steps(rnnt_ctx* ctx, hipStream_t s, int n, int n_frames) {
+    int rc;
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->n_active + 2, n_frames, 1LL);
+    LAUNCHCHK("fill_i32");
+    ctx->greedy_steps += n;
+    if (!ctx->use_graphs || ctx->prof_tag >= 20) return greedy_steps_raw(ctx, s, n);   // decode sites being timed: eager
+    for (auto& g : ctx->dec_graphs)
+        if (g.n_streams == ctx->n_streams && g.k == n) {
+            HIPCHK(hipGraphLaunch(g.exec, s));
+            ctx->launches += 4 * n;
+            return RNNT_OK;
+        }
+    if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    const int64_t l0 = ctx->launches;
+    HIPCHK(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    rc = greedy_steps_raw(ctx, ctx->cap_stream, n);
+    ctx->capturing = false;
+    hipError_t e = hipStreamEndCapture(ctx->cap_stream, &graph);
+    ctx->launches = l0;
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(ctx, RNNT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(ctx, RNNT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    ctx->dec_graphs.push_back({ctx->n_streams, n, exec});
+    HIPCHK(hipGraphLaunch(exec, s));
+    ctx->launches += 4 * n;
+    return RNNT_OK;
+}
+
+// run step batches until every stream has consumed all n_frames frames (host checks a device counter)
+int greedy_drain(rnnt_ctx* ctx, hipStream_t s, int n_frames, int done_steps) {
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->n_active + 2, n_frames, 1LL);
+    LAUNCHCHK("fill_i32");
+    const int max_steps = (n_frames - ctx->frames_decoded) * (ctx->cfg.n_steps + 1) + 8;
+    int rc;
+    while (true) {
+        // apply the last evaluation and count the streams that still have frames
+        hipLaunchKernelGGL(greedy_decide, dim3(1), dim3(64), 0, s, ctx->n_streams, ctx->cfg.blank_id, ctx->cfg.n_steps, ctx->cfg.max_tokens, 1,
+                           greedy_state(ctx));
+        LAUNCHCHK("greedy_decide");
+        HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (ctx->pinned[0] <= 0) break;
+        if (done_steps > max_steps) return fail(ctx, RNNT_ERR_STATE, "greedy decode did not terminate");
+        if ((rc = greedy_steps(ctx, s, 4, n_frames))) return rc;
+        done_steps += 4;
+    }
     return RNNT_OK;
 }
 
@@ -391,6 +513,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
         cfg->n_steps < 1 || cfg->max_beam < 0 || cfg->max_beam > 64)
         return fail(ctx, RNNT_ERR_ARG, "rnnt_create: bad config");
     HIPCHK(hipSetDevice(cfg->device));
+    if (const char* ng = getenv("RNNT_NO_GRAPH")) ctx->use_graphs = (ng[0] == '1') ? 0 : 1;
     const int B = cfg->max_streams;
     ctx->tmax = sub_len(cfg->max_chunk_frames);
     ctx->t1max = sub1_len(cfg->max_chunk_frames);
@@ -415,7 +538,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     ALLOC(xring, (size_t)L * B * ctx->cap * D);
     ALLOC(encbuf, (size_t)B * ctx->fstride * D);
     ALLOC(encp, (size_t)B * ctx->fstride * D);
-    ALLOC(h, (size_t)B * D); ALLOC(c, (size_t)B * D); ALLOC(h2, (size_t)B * D); ALLOC(c2, (size_t)B * D);
+    ALLOC(h, (size_t)2 * B * D); ALLOC(c, (size_t)2 * B * D); ALLOC(sel, B); ALLOC(key, B);
     ALLOC(pred, (size_t)B * D); ALLOC(z, (size_t)B * D); ALLOC(logits, (size_t)B * ctx->vpad);
     ALLOC(tok, B); ALLOC(fidx, B); ALLOC(nsym, B); ALLOC(count, B); ALLOC(tokens, (size_t)B * cfg->max_tokens);
     ALLOC(n_active, 4); ALLOC(klen, B);
@@ -440,7 +563,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
 void rnnt_destroy(rnnt_ctx* ctx) {
     if (!ctx) return;
     void* ptrs[] = {ctx->blob, ctx->egate, ctx->y1, ctx->y2, ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf, ctx->kcache, ctx->vcache,
-                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->h2, ctx->c2, ctx->pred, ctx->z, ctx->logits,
+                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->pred, ctx->z, ctx->logits,
                     ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch,
                     ctx->pool[0], ctx->pool[1], ctx->bpred, ctx->bz, ctx->blogits, ctx->b_blank, ctx->b_toplp, ctx->b_toptok,
                     ctx->b_tok, ctx->b_frame, ctx->b_active, ctx->b_steps, ctx->b_srcrow, ctx->b_srcstep};
@@ -450,6 +573,10 @@ void rnnt_destroy(rnnt_ctx* ctx) {
         if (ctx->lw[l].ptab) (void)hipFree(ctx->lw[l].ptab);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->wf_ev) (void)hipEventDestroy(e);
+    if (ctx->dec_stream) (void)hipStreamDestroy(ctx->dec_stream);
+    for (auto& g : ctx->dec_graphs) (void)hipGraphExecDestroy(g.exec);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     void* wf[] = {ctx->wf_x, ctx->wf_h, ctx->wf_q, ctx->wf_a, ctx->wf_d, ctx->wf_y1, ctx->wf_y2, ctx->wf_starts, ctx->wf_gtab, ctx->wf_atab,
                   ctx->wf_dtab, ctx->wf_ltab};
     for (void* q : wf)
@@ -627,6 +754,21 @@ int rnnt_finalize_weights(rnnt_ctx* ctx, int32_t numerics_mode, void* stream) {
         put(&ctx->wenc, wen->data.data(), wen->data.size()); put(&ctx->benc, ben->data.data(), D);
         put(&ctx->wpf, wpf->data.data(), wpf->data.size()); put(&ctx->bpf, bpf->data.data(), D);
         put(&ctx->wout, wou->data.data(), wou->data.size()); put(&ctx->bout, bou->data.data(), V);
+        // greedy decode only needs pred_ffn(projection(h)): fold the two Linears (joint.py:54, predictor.py:205) into
+        // W_c = W_pf * W_pr, b_c = W_pf * b_pr + b_pf (accumulated in double, stored in float32)
+        std::vector<float> wc((size_t)D * D), bc(D);
+        for (int n = 0; n < D; ++n) {
+            for (int k = 0; k < D; ++k) {
+                double acc = 0.0;
+                for (int j = 0; j < D; ++j) acc += (double)wpf->data[(size_t)n * D + j] * (double)wpr->data[(size_t)j * D + k];
+                wc[(size_t)n * D + k] = (float)acc;
+            }
+            double acc = bpf->data[n];
+            for (int j = 0; j < D; ++j) acc += (double)wpf->data[(size_t)n * D + j] * (double)bpr->data[j];
+            bc[n] = (float)acc;
+        }
+        putv(&ctx->wjc, wc);
+        putv(&ctx->bjc, bc);
     }
 #undef NEED
     // upload
@@ -666,8 +808,10 @@ int rnnt_streams_reset(rnnt_ctx* ctx, int32_t n_streams, void* stream) {
     ctx->launches = 0; ctx->greedy_steps = 0;
     hipLaunchKernelGGL(conv_ring_init, dim3(grid_for((long long)L * B * ctx->cap * D)), dim3(256), 0, s, ctx->gring, ctx->xring, ctx->glu0, B, ctx->cap);
     LAUNCHCHK("conv_ring_init");
-    HIPCHK(hipMemsetAsync(ctx->h, 0, (size_t)B * D * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(ctx->c, 0, (size_t)B * D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(ctx->h, 0, (size_t)2 * B * D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(ctx->c, 0, (size_t)2 * B * D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(ctx->sel, 0, B * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(ctx->key, 0, B * sizeof(unsigned long long), s));
     HIPCHK(hipMemsetAsync(ctx->fidx, 0, B * sizeof(int), s));
     HIPCHK(hipMemsetAsync(ctx->nsym, 0, B * sizeof(int), s));
     HIPCHK(hipMemsetAsync(ctx->count, 0, B * sizeof(int), s));
@@ -728,7 +872,8 @@ int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t T, int32_t
 // chunk c and layer l's K/V + conv caches after chunk c-1), so the dependent-launch chain is
 // (n_chunks + 11) stages instead of 12 * n_chunks; (c) after_norm + joint.enc_ffn for all new frames at once.
 int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_frames, int32_t n_chunks, const int32_t* chunk_start,
-                        const int32_t* chunk_len, const int32_t* offsets, const int32_t* required, int32_t* frames_out, void* stream) {
+                        const int32_t* chunk_len, const int32_t* offsets, const int32_t* required, int32_t greedy, int32_t* frames_out,
+                        void* stream) {
     if (!ctx || !fbank_dev || !chunk_start || !chunk_len || !offsets || !required || n_chunks < 1)
         return fail(ctx, RNNT_ERR_ARG, "rnnt_encoder_chunks: bad argument");
     if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_encoder_chunks: no weights / no streams");
@@ -837,14 +982,6 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         seq.push_back({12, (int)lt.size(), n, maxM});
         for (auto& d : cur) lt.push_back(d.lnf);
     }
-    // (c) after_norm of every chunk straight into the frame buffer
-    int maxMc = 0;
-    const int ln_after_off = (int)lt.size();
-    for (int c = 0; c < C; ++c) {
-        lt.push_back(LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
-                         (long long)ctx->fstride * D, (long long)D});
-        if (B * ci[c].tq > maxMc) maxMc = B * ci[c].tq;
-    }
     if ((rc = grow(ctx, &ctx->wf_gtab, &ctx->wf_gcap, gt.size()))) return rc;
     if ((rc = grow(ctx, &ctx->wf_atab, &ctx->wf_acap, at.size()))) return rc;
     if ((rc = grow(ctx, &ctx->wf_dtab, &ctx->wf_dcap, dt.size()))) return rc;
@@ -857,34 +994,95 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     static const int gN[8] = {FF, D, D, D, 2 * D, D, FF, D};
     static const int gK[8] = {D, FF, D, D, D, D, D, FF};
     static const int gTag[8] = {TAG_FFN1, TAG_FFN2, TAG_QKV, TAG_ATTN_OUT, TAG_PW1, TAG_PW2, TAG_FFN1, TAG_FFN2};
-    for (const Launch& q : seq) {
-        if (q.type < 8) {
-            if ((rc = launch_gemm_tab(ctx, s, ctx->wf_gtab + q.off, q.n, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
-        } else if (q.type == 10) {
-            ProfScope prof(ctx, s, TAG_ATTN);
-            dim3 grid(B * RNNT_H, (q.maxM + ATT_QB - 1) / ATT_QB, q.n);
-            hipLaunchKernelGGL(rel_attention_tab, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
-            LAUNCHCHK("rel_attention_tab");
-        } else if (q.type == 11) {
-            ProfScope prof(ctx, s, TAG_DWCONV);
-            hipLaunchKernelGGL(dwconv_bn_silu_tab, dim3(grid_for((long long)q.maxM * D), 1, q.n), dim3(256), 0, s, ctx->wf_dtab + q.off);
-            LAUNCHCHK("dwconv_bn_silu_tab");
-        } else {
-            hipLaunchKernelGGL(layer_norm_tab, dim3((q.maxM + 3) / 4, 1, q.n), dim3(256), 0, s, ctx->wf_ltab + q.off);
-            LAUNCHCHK("layer_norm_tab");
+    // decode stream + events (greedy != 0): chunk c's frames are decodable once its layer-11 stage, after_norm and
+    // joint.enc_ffn projection are done; the greedy steps run on ctx->dec_stream concurrently with later stages.
+    hipStream_t s2 = s;
+    if (greedy) {
+        if (!ctx->dec_stream) {   // decode = the latency-critical dependent chain: highest stream priority
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char* pe = getenv("RNNT_DEC_PRIO");
+            const int prio = (pe && pe[0] == '0') ? lo : hi;
+            const char* me = getenv("RNNT_DEC_CUS");   // experiment: reserve the first n CUs of every XCD-interleaved mask for decode
+            const int ncu = me ? atoi(me) : 0;
+            if (ncu > 0) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+                HIPCHK(hipExtStreamCreateWithCUMask(&ctx->dec_stream, 8, mask));
+            } else {
+                HIPCHK(hipStreamCreateWithPriority(&ctx->dec_stream, hipStreamNonBlocking, prio));
+            }
+        }
+        s2 = ctx->dec_stream;
+        while ((int)ctx->wf_ev.size() < C + 1) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->wf_ev.push_back(e);
+        }
+        HIPCHK(hipEventRecord(ctx->wf_ev[C], s));          // everything enqueued before this call (reset, earlier decode)
+        HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[C], 0));
+    }
+    int dec_steps = 0;
+    const int fb0 = ctx->frames_buffered;
+    size_t qi = 0;
+    static const bool timing = getenv("RNNT_TIMING") != nullptr;
+    double t_enc = 0, t_dec = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tl = now();
+    for (int st = 0; st < C + L - 1; ++st) {
+        for (int j = 0; j < 11 && qi < seq.size(); ++j, ++qi) {
+            const Launch& q = seq[qi];
+            if (q.type < 8) {
+                if ((rc = launch_gemm_tab(ctx, s, ctx->wf_gtab + q.off, q.n, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
+            } else if (q.type == 10) {
+                ProfScope prof(ctx, s, TAG_ATTN);
+                const int nq = q.maxM <= 4 ? 1 : (q.maxM <= 8 ? 2 : 4);
+                dim3 grid(B * RNNT_H, (q.maxM + 4 * nq - 1) / (4 * nq), q.n);
+                if (nq == 1) hipLaunchKernelGGL(rel_attention_tab<1>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
+                else if (nq == 2) hipLaunchKernelGGL(rel_attention_tab<2>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
+                else hipLaunchKernelGGL(rel_attention_tab<4>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
+                LAUNCHCHK("rel_attention_tab");
+            } else if (q.type == 11) {
+                ProfScope prof(ctx, s, TAG_DWCONV);
+                hipLaunchKernelGGL(dwconv_bn_silu_tab, dim3(grid_for((long long)q.maxM * D), 1, q.n), dim3(256), 0, s, ctx->wf_dtab + q.off);
+                LAUNCHCHK("dwconv_bn_silu_tab");
+            } else {
+                hipLaunchKernelGGL(layer_norm_tab, dim3((q.maxM + 3) / 4, 1, q.n), dim3(256), 0, s, ctx->wf_ltab + q.off);
+                LAUNCHCHK("layer_norm_tab");
+            }
+        }
+        const int c = st - (L - 1);   // chunk whose last block just ran
+        if (c < 0) continue;
+        // (c) after_norm straight into the frame buffer + joint.enc_ffn projection of the chunk's frames
+        if ((rc = launch_ln(ctx, s, LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
+                                        (long long)ctx->fstride * D, (long long)D}))) return rc;
+        {
+            const int F = ci[c].tq;
+            GemmP g = plain_gemm(ctx->encbuf + (size_t)ci[c].fpos * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * F, D, D);
+            g.a_n1 = F; g.a_n2 = F; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
+            g.c_n = F; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ci[c].fpos; g.c_mod = BIG; g.c_s1 = D;
+            if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
+        }
+        if (timing) { double t = now(); t_enc += t - tl; tl = t; }
+        if (greedy) {
+            HIPCHK(hipEventRecord(ctx->wf_ev[c], s));
+            HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c], 0));
+            static const int slack = getenv("RNNT_DEC_SLACK") ? atoi(getenv("RNNT_DEC_SLACK")) : 8;
+            const int budget = ci[c].tq + slack;   // frames + typical symbols; stragglers are finished by the drain below
+            if ((rc = greedy_steps(ctx, s2, budget, ci[c].fpos + ci[c].tq))) return rc;
+            dec_steps += budget;
+            if (timing) { double t = now(); t_dec += t - tl; tl = t; }
         }
     }
-    hipLaunchKernelGGL(layer_norm_tab, dim3((maxMc + 3) / 4, 1, C), dim3(256), 0, s, ctx->wf_ltab + ln_after_off);
-    LAUNCHCHK("layer_norm_tab");
-    {
-        const int F = fb - ctx->frames_buffered;   // new frames per stream
-        GemmP g = plain_gemm(ctx->encbuf + (size_t)ctx->frames_buffered * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * F, D, D);
-        g.a_n1 = F; g.a_n2 = F; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
-        g.c_n = F; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ctx->frames_buffered; g.c_mod = BIG; g.c_s1 = D;
-        if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
-        if (frames_out) *frames_out = F;
-    }
+    if (timing) fprintf(stderr, "[rnnt timing] host enqueue: encoder stages %.2f ms, decode batches %.2f ms\n", t_enc, t_dec);
+    if (frames_out) *frames_out = fb - fb0;
     ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
+    if (greedy) {
+        if ((rc = greedy_drain(ctx, s2, fb, dec_steps))) return rc;   // synchronises the decode stream (=> encoder done too)
+        ctx->frames_decoded = fb;
+        HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));                    // later work on the caller's stream sees the decode
+        HIPCHK(hipStreamWaitEvent(s, ctx->wf_ev[C], 0));
+    }
     return RNNT_OK;
 }
 
@@ -892,42 +1090,12 @@ int rnnt_greedy_decode(rnnt_ctx* ctx, void* stream) {
     if (!ctx) return RNNT_ERR_ARG;
     if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_greedy_decode: no weights / no streams");
     hipStream_t s = (hipStream_t)stream;
-    const int B = ctx->n_streams, V = ctx->cfg.vocab_size;
     const int nf = ctx->frames_buffered;
     if (nf <= ctx->frames_decoded) return RNNT_OK;
     int rc;
-    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->n_active, B, 1LL);
-    LAUNCHCHK("fill_i32");
-    GreedyState st{ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->h, ctx->c, ctx->h2, ctx->c2};
-    int batch = nf - ctx->frames_decoded + 2;
-    const int max_steps = (nf - ctx->frames_decoded) * (ctx->cfg.n_steps + 1) + 1;
-    int done_steps = 0;
-    while (true) {
-        for (int it = 0; it < batch; ++it) {
-            // LSTM cell: gates = E[tok] + h * W_hh^T (predictor.py:200-204)
-            GemmP g1 = plain_gemm(ctx->h, D, ctx->whh_il, D, nullptr, ctx->h2, D, B, 4 * D, D, EPI_LSTM);
-            g1.X = ctx->egate; g1.I = ctx->tok; g1.X2 = ctx->c; g1.Y2 = ctx->c2;
-            if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_LSTM))) return rc;
-            GemmP g2 = plain_gemm(ctx->h2, D, ctx->wpr, D, ctx->bpr, ctx->pred, D, B, D, D);
-            if ((rc = launch_gemm(ctx, s, 0, &g2, 1, TAG_PRED_PROJ))) return rc;
-            // z = tanh(enc_ffn(enc)[t_b] + pred_ffn(pred)) (joint.py:54-66)
-            GemmP g3 = plain_gemm(ctx->pred, D, ctx->wpf, D, ctx->bpf, ctx->z, D, B, D, D, EPI_TANH_ADD);
-            g3.X = ctx->encp; g3.I = ctx->fidx; g3.x_n = 1; g3.x_s0 = (long long)ctx->fstride * D; g3.x_s1 = D;
-            if ((rc = launch_gemm(ctx, s, 0, &g3, 1, TAG_JOINT_TANH))) return rc;
-            GemmP g4 = plain_gemm(ctx->z, D, ctx->wout, D, ctx->bout, ctx->logits, ctx->vpad, B, V, D);
-            if ((rc = launch_gemm(ctx, s, 0, &g4, 1, TAG_JOINT_OUT))) return rc;
-            hipLaunchKernelGGL(greedy_update, dim3(B), dim3(64), 0, s, ctx->logits, ctx->vpad, V, ctx->cfg.blank_id, ctx->cfg.n_steps, nf,
-                               ctx->cfg.max_tokens, st);
-            LAUNCHCHK("greedy_update");
-        }
-        done_steps += batch;
-        ctx->greedy_steps += batch;
-        HIPCHK(hipMemcpyAsync(ctx->pinned, ctx->n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (ctx->pinned[0] <= 0) break;
-        if (done_steps > max_steps) return fail(ctx, RNNT_ERR_STATE, "greedy decode did not terminate");
-        batch = 4;
-    }
+    const int first = nf - ctx->frames_decoded + 2;
+    if ((rc = greedy_steps(ctx, s, first, nf))) return rc;
+    if ((rc = greedy_drain(ctx, s, nf, first))) return rc;
     ctx->frames_decoded = nf;
     return RNNT_OK;
 }
@@ -1148,8 +1316,11 @@ int rnnt_get_cnn_cache(rnnt_ctx* ctx, int32_t b, float* dst_host, void* stream) 
 int rnnt_get_predictor_state(rnnt_ctx* ctx, int32_t b, float* h_host, float* c_host, int32_t* last_token, void* stream) {
     if (!ctx || b < 0 || b >= ctx->n_streams) return fail(ctx, RNNT_ERR_ARG, "rnnt_get_predictor_state: bad stream index");
     hipStream_t s = (hipStream_t)stream;
-    if (h_host) HIPCHK(hipMemcpyAsync(h_host, ctx->h + (size_t)b * D, D * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (c_host) HIPCHK(hipMemcpyAsync(c_host, ctx->c + (size_t)b * D, D * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctx->pinned + 4, ctx->sel + b, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const size_t bo = (size_t)(ctx->pinned[4] & 1) * ctx->cfg.max_streams * D;   // committed buffer of this stream
+    if (h_host) HIPCHK(hipMemcpyAsync(h_host, ctx->h + bo + (size_t)b * D, D * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (c_host) HIPCHK(hipMemcpyAsync(c_host, ctx->c + bo + (size_t)b * D, D * sizeof(float), hipMemcpyDeviceToHost, s));
     if (last_token) HIPCHK(hipMemcpyAsync(last_token, ctx->tok + b, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return RNNT_OK;

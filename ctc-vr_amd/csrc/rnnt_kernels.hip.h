@@ -40,7 +40,7 @@ enum {
     EPI_GLU = 5,       // interleaved (a,gate) columns -> C[:, n/2] = a * sigmoid(gate)
     EPI_LSTM = 6,      // interleaved (i,f,g,o) columns + input table row -> h', c'
     EPI_TANH_ADD = 7,  // C = tanh(acc + bias + X[gather(m)][n])   (joint: enc_proj[t_b] + pred_proj)
-    EPI_LOGSOFTMAX_PREP = 8  // unused placeholder
+    EPI_ARGMAX = 8     // no store: per-row argmax of (acc + bias) over all columns into key[m] (greedy decode)
 };
 
 struct GemmP {
@@ -77,12 +77,41 @@ struct GemmP {
     // (q = umulhi(n, magic), exact while n*d < 2^32; see fastdiv()).
     int a_plain, c_plain;
     int lstm_ld;   // EPI_LSTM: row stride (floats) of X2 / C / Y2; 0 -> 256
+    // greedy decode: per-row buffer select (LSTM state ping-pong) and fused argmax
+    const int* Asel;             // [M] 0/1: A row m lives in buffer Asel[m] (^ asel_invert); null = off
+    long long asel_stride;       // floats between the two buffers (also used by the EPI_LSTM state rows when Asel != null)
+    int asel_invert;
+    unsigned long long* key;     // EPI_ARGMAX: per-row packed (ordered value, ~index) maximum, atomicMax
+    const int* nframes;          // EPI_ARGMAX: rows with I[m] >= *nframes are idle (no key written)
+    int dbg;       // microbenchmark ablation bits (0 in production): 1 skip global loads, 2 skip MFMAs, 4 skip epilogue
     unsigned a_n1_magic, a_n2_magic, a_seg_magic, c_n_magic, x_n_magic;
 };
 
 struct GemmBatch {
     GemmP g[3];
 };
+
+// Explicit global-address-space accesses.  Pointers that come out of an in-memory descriptor are "generic" to the
+// compiler, which then emits flat_load/flat_store: those count on BOTH vmcnt and lgkmcnt, so every wait for an LDS
+// read also drains the global loads in flight and nothing overlaps.  These helpers force global_load/global_store.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RNNT_GAS __attribute__((address_space(1)))
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const f32x4g v = *(const RNNT_GAS f32x4g*)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float ldg1(const float* p) { return *(const RNNT_GAS float*)p; }
+__device__ __forceinline__ int ldgi(const int* p) { return *(const RNNT_GAS int*)p; }
+__device__ __forceinline__ void stg1(float* p, float v) { *(RNNT_GAS float*)p = v; }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *(RNNT_GAS f32x4g*)p = (f32x4g){v.x, v.y, v.z, v.w}; }
+#else   // host pass of the single-source compile: never executed
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float ldg1(const float* p) { return *p; }
+__device__ __forceinline__ int ldgi(const int* p) { return *p; }
+__device__ __forceinline__ void stg1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#endif
 
 __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {   // exact for n*d < 2^32
     return d == 1 ? n : (int)__umulhi((unsigned)n, magic);
@@ -309,30 +338,39 @@ __device__ __forceinline__ long long c_row_off(const GemmP& p, int m) {
     return (long long)q * p.c_s0 + (long long)r * p.c_s1;
 }
 
-template <int WK, int NT>
+template <int WK, int MT, int NT>
 __device__ __forceinline__ void gemm16_body(const GemmP& p) {
-    __shared__ __attribute__((aligned(16))) float part[WK * NT * 256];
-    __shared__ float st[32];
+    // tile = (16*MT) x (16*NT) outputs per workgroup; every wave holds the full MT x NT accumulator set for its
+    // K-slice, so one float4 of A feeds NT MFMAs and one float4 of W feeds MT (operand reuse in registers).
+    __shared__ __attribute__((aligned(16))) float part[WK * MT * NT * 256];
+    __shared__ float st[32 * MT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * (16 * NT);
+    const int m0 = blockIdx.y * (16 * MT), n0 = blockIdx.x * (16 * NT);
     if (m0 >= p.M || n0 >= p.N) return;
     const int i = lane & 15, kq = lane >> 4;
 
-    const int am = min(m0 + i, p.M - 1);
-    const float* arow = p.A + a_row_off(p, am);
+    const float* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int am = min(m0 + 16 * mt + i, p.M - 1);
+        arow[mt] = p.A + a_row_off(p, am);
+        if (p.Asel) arow[mt] += (long long)(ldgi(p.Asel + am) ^ p.asel_invert) * p.asel_stride;
+    }
     const float* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wrow[t] = p.W + (long long)min(n0 + 16 * t + i, p.N - 1) * p.ldw;
 
-    float mean = 0.f, rstd = 1.f;
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { mean[mt] = 0.f; rstd[mt] = 1.f; }
     const bool ln = p.ln_g != nullptr;
     if (ln) {
         const int grp = tid >> 4, l16 = tid & 15;
-        for (int r = grp; r < 16; r += 4 * WK) {
+        for (int r = grp; r < 16 * MT; r += 4 * WK) {
             const float* rp = p.A + a_row_off(p, min(m0 + r, p.M - 1));
             float4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(rp + 4 * (l16 + 16 * j));
+            for (int j = 0; j < 4; ++j) v[j] = ldg4(rp + 4 * (l16 + 16 * j));
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -353,78 +391,135 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
             }
         }
         __syncthreads();
-        mean = st[i * 2];
-        rstd = st[i * 2 + 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            mean[mt] = st[(16 * mt + i) * 2];
+            rstd[mt] = st[(16 * mt + i) * 2 + 1];
+        }
     }
 
-    f32x4_ acc[NT];
+    f32x4_ acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
 
     const int ks = p.K / WK;
     const int k0 = wave * ks, kend = k0 + ks;
+    constexpr int UN = (MT * NT >= 8) ? 2 : 4;   // k-steps of 16 in flight per iteration (register budget)
     int k = k0;
-    for (; k + 64 <= kend; k += 64) {
-        float4 a[4], w[4][NT];
+    for (; k + 16 * UN <= kend; k += 16 * UN) {
+        float4 a[UN][MT], w[UN][NT];
+        if (p.dbg & 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[u][mt] = make_float4(1.f * k, 2.f, 3.f, 4.f + lane);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) w[u][t] = make_float4(1.f, 2.f * k, 3.f + lane, 4.f);
+            }
+        } else {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
             const int kk = k + 16 * u + 4 * kq;
-            a[u] = *reinterpret_cast<const float4*>(arow + a_k_off(p, kk));
+            const long long ko = a_k_off(p, kk);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w[u][t] = *reinterpret_cast<const float4*>(wrow[t] + kk);
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = ldg4(arow[mt] + ko);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[u][t] = ldg4(wrow[t] + kk);
+        }
         }
         if (ln) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const int kk = k + 16 * u + 4 * kq;
-                const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
-                const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
-                a[u].x = (a[u].x - mean) * rstd * g.x + b.x;
-                a[u].y = (a[u].y - mean) * rstd * g.y + b.y;
-                a[u].z = (a[u].z - mean) * rstd * g.z + b.z;
-                a[u].w = (a[u].w - mean) * rstd * g.w + b.w;
+                const float4 g = ldg4(p.ln_g + kk);
+                const float4 b = ldg4(p.ln_b + kk);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    a[u][mt].x = (a[u][mt].x - mean[mt]) * rstd[mt] * g.x + b.x;
+                    a[u][mt].y = (a[u][mt].y - mean[mt]) * rstd[mt] * g.y + b.y;
+                    a[u][mt].z = (a[u][mt].z - mean[mt]) * rstd[mt] * g.z + b.z;
+                    a[u][mt].w = (a[u][mt].w - mean[mt]) * rstd[mt] * g.w + b.w;
+                }
             }
         }
+        if (p.dbg & 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, w[u][t].x, acc[t], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, w[u][t].y, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) acc[mt][t][0] += a[u][mt].x * w[u][t].x + a[u][mt].y * w[u][t].y + a[u][mt].z * w[u][t].z + a[u][mt].w * w[u][t].w;
+        } else
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, w[u][t].z, acc[t], 0, 0, 0);
+        for (int u = 0; u < UN; ++u) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, w[u][t].w, acc[t], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt].x, w[u][t].x, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt].y, w[u][t].y, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt].z, w[u][t].z, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt].w, w[u][t].w, acc[mt][t], 0, 0, 0);
         }
     }
     for (; k + 16 <= kend; k += 16) {
         const int kk = k + 4 * kq;
-        float4 a = *reinterpret_cast<const float4*>(arow + a_k_off(p, kk));
+        const long long ko = a_k_off(p, kk);
+        float4 a[MT], w[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = ldg4(arow[mt] + ko);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = ldg4(wrow[t] + kk);
         if (ln) {
-            const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
-            const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
-            a.x = (a.x - mean) * rstd * g.x + b.x;
-            a.y = (a.y - mean) * rstd * g.y + b.y;
-            a.z = (a.z - mean) * rstd * g.z + b.z;
-            a.w = (a.w - mean) * rstd * g.w + b.w;
+            const float4 g = ldg4(p.ln_g + kk);
+            const float4 b = ldg4(p.ln_b + kk);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                a[mt].x = (a[mt].x - mean[mt]) * rstd[mt] * g.x + b.x;
+                a[mt].y = (a[mt].y - mean[mt]) * rstd[mt] * g.y + b.y;
+                a[mt].z = (a[mt].z - mean[mt]) * rstd[mt] * g.z + b.z;
+                a[mt].w = (a[mt].w - mean[mt]) * rstd[mt] * g.w + b.w;
+            }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 w = *reinterpret_cast<const float4*>(wrow[t] + kk);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[t], 0, 0, 0);
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, w[t].x, acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, w[t].y, acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, w[t].z, acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, w[t].w, acc[mt][t], 0, 0, 0);
+            }
     }
 
+    if (p.dbg & 4) {   // ablation: keep the accumulators alive, skip reduction and epilogue
+        float sacc = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) sacc += acc[mt][t][0] + acc[mt][t][1] + acc[mt][t][2] + acc[mt][t][3];
+        if (sacc == 12345.678f) p.C[0] = sacc;
+        return;
+    }
     // deterministic split-K reduction through LDS (fixed wave order)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) part[(wave * NT + t) * 256 + r * 64 + lane] = acc[t][r];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[((wave * MT + mt) * NT + t) * 256 + r * 64 + lane] = acc[mt][t][r];
     __syncthreads();
-    constexpr int NTH = 64 * WK, NEL = NT * 256;
+    constexpr int NTH = 64 * WK, NEL = MT * NT * 256;
     const int epi = p.epi;
     const bool paired = (epi == EPI_GLU || epi == EPI_LSTM);
     for (int e0 = 0; e0 < NEL; e0 += NTH) {
@@ -435,58 +530,280 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
 #pragma unroll
             for (int w2 = 1; w2 < WK; ++w2) sum += part[w2 * NEL + idx];
         }
-        const int t = idx >> 8, rem = idx & 255;
+        const int tile = idx >> 8, rem = idx & 255;
+        const int mt = tile / NT, t = tile - mt * NT;
         const int reg = rem >> 6, ln_ = rem & 63;
-        const int row = (ln_ >> 4) * 4 + reg, col = 16 * t + (ln_ & 15);
+        const int row = 16 * mt + (ln_ >> 4) * 4 + reg, col = 16 * t + (ln_ & 15);
         const int m = m0 + row, n = n0 + col;
         const bool inb = idx < NEL && m < p.M && n < p.N;
         if (paired) {
             __syncthreads();   // all partial reads of this pass done before slot 0 is overwritten
-            if (idx < NEL) part[idx] = sum + (p.bias ? p.bias[min(n, p.N - 1)] : 0.f);
+            if (idx < NEL) part[idx] = sum + (p.bias ? ldg1(p.bias + min(n, p.N - 1)) : 0.f);
             __syncthreads();
             if (!inb) continue;
             if (epi == EPI_GLU) {
                 if (col & 1) continue;
                 const float a = part[idx], g = part[idx + 1];
-                p.C[c_row_off(p, m) + (n >> 1)] = a * sigmoidf_(g);
+                stg1(p.C + c_row_off(p, m) + (n >> 1), a * sigmoidf_(g));
             } else {
                 if (col & 3) continue;
-                const int tok = p.I[m];
-                const float4 tb = *reinterpret_cast<const float4*>(p.X + (long long)tok * (4 * RNNT_D) + n);
+                const int tok = ldgi(p.I + m);
+                const float4 tb = ldg4(p.X + (long long)tok * (4 * RNNT_D) + n);
                 const float gi = part[idx] + tb.x, gf = part[idx + 1] + tb.y, gg = part[idx + 2] + tb.z, go = part[idx + 3] + tb.w;
                 const int j = n >> 2;
-                const long long so = (long long)m * (p.lstm_ld ? p.lstm_ld : RNNT_D) + j;
-                const float cin = p.X2[so];
+                long long si = (long long)m * (p.lstm_ld ? p.lstm_ld : RNNT_D) + j, so = si;
+                if (p.Asel) {   // committed state in buffer sel, candidate written to the other buffer
+                    const int sl = ldgi(p.Asel + m);
+                    si += (long long)sl * p.asel_stride;
+                    so += (long long)(sl ^ 1) * p.asel_stride;
+                }
+                const float cin = ldg1(p.X2 + si);
                 const float c2 = sigmoidf_(gf) * cin + sigmoidf_(gi) * tanhf(gg);
-                p.C[so] = sigmoidf_(go) * tanhf(c2);
-                p.Y2[so] = c2;
+                stg1(p.C + so, sigmoidf_(go) * tanhf(c2));
+                stg1(p.Y2 + so, c2);
+            }
+            continue;
+        }
+        if (epi == EPI_ARGMAX) {
+            // 16 consecutive lanes hold the 16 columns of one row of this tile: reduce, then one atomicMax per row.
+            float v = inb ? sum + (p.bias ? ldg1(p.bias + n) : 0.f) : -INFINITY;
+            int bi = inb ? n : 0x7fffffff;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 16);
+                const int oi = __shfl_xor(bi, o, 16);
+                if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; }
+            }
+            if ((ln_ & 15) == 0 && idx < NEL && m < p.M && bi != 0x7fffffff && ldgi(p.I + m) < ldgi(p.nframes)) {
+                unsigned u = __float_as_uint(v);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // order-preserving float -> uint
+                const unsigned long long k64 = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
+                atomicMax(p.key + m, k64);                        // max value, lowest index on ties (torch.argmax)
             }
             continue;
         }
         if (!inb) continue;
         const long long crow = c_row_off(p, m);
-        float v = sum + (p.bias ? p.bias[n] : 0.f);
+        float v = sum + (p.bias ? ldg1(p.bias + n) : 0.f);
         if (epi == EPI_SILU) v = v * sigmoidf_(v);
         else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
         else if (epi == EPI_SCALE) v = v * p.alpha;
-        else if (epi == EPI_RESID) v = p.R[crow + n] + p.alpha * v;
+        else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
         else if (epi == EPI_TANH_ADD) {
             const int bi = fastdiv(m, p.x_n, p.x_n_magic);
-            const int fr = p.I ? p.I[bi] : (m - bi * p.x_n);
-            v = tanhf(v + p.X[(long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n]);
+            const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
+            v = tanhf(v + ldg1(p.X + (long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n));
         }
-        p.C[crow + n] = v;
+        stg1(p.C + crow + n, v);
     }
 }
 
-template <int WK, int NT>
+template <int WK, int MT, int NT>
 __global__ __launch_bounds__(64 * WK) void gemm16(GemmBatch gb) {
-    gemm16_body<WK, NT>(gb.g[blockIdx.z]);
+    gemm16_body<WK, MT, NT>(gb.g[blockIdx.z]);
 }
 // table-driven variant: one descriptor per blockIdx.z in device memory (wavefront schedule: up to 36 groups)
-template <int WK, int NT>
+template <int WK, int MT, int NT>
 __global__ __launch_bounds__(64 * WK) void gemm16_tab(const GemmP* __restrict__ tab) {
-    gemm16_body<WK, NT>(tab[blockIdx.z]);
+    const GemmP p = tab[blockIdx.z];
+    gemm16_body<WK, MT, NT>(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_ns<MT,NT>: grouped-launch GEMM, LDS-tiled, no split-K.  Workgroup = 4 waves (2x2), workgroup tile
+// (32*MT) x (32*NT), each wave a (16*MT) x (16*NT) sub-tile over the full K; epilogue straight from the accumulators.
+// Operands go global -> registers -> LDS in FULL 128-byte lines (8 consecutive lanes read one row's 32 floats):
+// rocprofv3 showed that fragment-shaped loads (consecutive lanes = different rows) cost ~64 L1 accesses per wave
+// instruction and held the MFMA pipe at 20 %.  K advances in blocks of 32 with two LDS buffers; the global loads of
+// block b+1 are issued before the MFMAs of block b and written to LDS after them (one barrier per block).
+// LDS rows are padded to 36 floats: the 16 rows of a ds_read_b128 fragment read start on 16 distinct 4-bank groups.
+// The LayerNorm prologue is applied while the A tile is written to LDS.
+// ------------------------------------------------------------------------------------------------
+#define NS_BK 32
+#define NS_LD 36
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * NS_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[2][BN * NS_LD];
+    __shared__ float st[2 * BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = by * BM, bn0 = bx * BN;
+    if (bm0 >= p.M || bn0 >= p.N) return;   // whole workgroup out of range (uniform)
+    const int i = lane & 15, kq = lane >> 4;
+    const bool ln = p.ln_g != nullptr;
+    if (ln) {
+        const int grp = tid >> 4, l16 = tid & 15;
+        for (int r = grp; r < BM; r += 16) {
+            const float* rp = p.A + a_row_off(p, min(bm0 + r, p.M - 1));
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ldg4(rp + 4 * (l16 + 16 * j));
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+            const float mu = sm * (1.0f / 256.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = v[j].x - mu, dy = v[j].y - mu, dz = v[j].z - mu, dw = v[j].w - mu;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 16);
+            if (l16 == 0) {
+                st[r * 2] = mu;
+                st[r * 2 + 1] = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+            }
+        }
+        __syncthreads();
+    }
+
+    // staging assignment: float4 slot s = tid + 256*j covers tile row s/8, columns 4*(s%8)..+3
+    const int c4 = (tid & 7) * 4;
+    const int srow = tid >> 3;
+    const float* ag[MT];
+    const float* wg[NT];
+    float amean[MT], arstd[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int am = min(bm0 + srow + 32 * j, p.M - 1);
+        ag[j] = p.A + a_row_off(p, am);
+        if (p.Asel) ag[j] += (long long)(ldgi(p.Asel + am) ^ p.asel_invert) * p.asel_stride;
+        amean[j] = ln ? st[(srow + 32 * j) * 2] : 0.f;
+        arstd[j] = ln ? st[(srow + 32 * j) * 2 + 1] : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wg[j] = p.W + (long long)min(bn0 + srow + 32 * j, p.N - 1) * p.ldw;
+
+    f32x4_ acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = (wave >> 1) * (16 * MT), wn = (wave & 1) * (16 * NT);   // this wave's sub-tile inside the workgroup tile
+    const int nb = p.K / NS_BK;
+    const bool aplain = p.a_plain != 0;
+    float4 ra[MT], rw[NT], rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define NS_GLOAD(blk_)                                                                                         \
+    {                                                                                                          \
+        const int kk_ = (blk_) * NS_BK + c4;                                                                   \
+        const long long ko_ = aplain ? (long long)kk_ : a_k_off(p, kk_);                                       \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j) ra[j] = ldg4(ag[j] + ko_);                              \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) rw[j] = ldg4(wg[j] + kk_);                              \
+        if (ln) {                                                                                              \
+            rg = ldg4(p.ln_g + kk_);                                                                           \
+            rb = ldg4(p.ln_b + kk_);                                                                           \
+        }                                                                                                      \
+    }
+#define NS_LSTORE(buf_)                                                                                        \
+    {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j) {                                                       \
+            float4 v_ = ra[j];                                                                                 \
+            if (ln) {                                                                                          \
+                v_.x = (v_.x - amean[j]) * arstd[j] * rg.x + rb.x;                                             \
+                v_.y = (v_.y - amean[j]) * arstd[j] * rg.y + rb.y;                                             \
+                v_.z = (v_.z - amean[j]) * arstd[j] * rg.z + rb.z;                                             \
+                v_.w = (v_.w - amean[j]) * arstd[j] * rg.w + rb.w;                                             \
+            }                                                                                                  \
+            *reinterpret_cast<float4*>(&As[buf_][(srow + 32 * j) * NS_LD + c4]) = v_;                          \
+        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
+            *reinterpret_cast<float4*>(&Ws[buf_][(srow + 32 * j) * NS_LD + c4]) = rw[j];                       \
+    }
+
+    NS_GLOAD(0)
+    NS_LSTORE(0)
+    __syncthreads();
+    for (int blk = 0; blk < nb; ++blk) {
+        const int buf = blk & 1;
+        if (blk + 1 < nb) NS_GLOAD(blk + 1)
+#pragma unroll
+        for (int u = 0; u < NS_BK / 16; ++u) {
+            float4 a[MT], w[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(&As[buf][(wm + 16 * mt + i) * NS_LD + 16 * u + 4 * kq]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const float4*>(&Ws[buf][(wn + 16 * t + i) * NS_LD + 16 * u + 4 * kq]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, w[t].x, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, w[t].y, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, w[t].z, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, w[t].w, acc[mt][t], 0, 0, 0);
+        }
+        if (blk + 1 < nb) NS_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef NS_GLOAD
+#undef NS_LSTORE
+    const int m0 = bm0 + wm, n0 = bn0 + wn;
+    if (m0 >= p.M || n0 >= p.N) return;     // this wave's sub-tile is out of range (all barriers are behind us)
+
+    // epilogue straight from the accumulators: lane (i, kq) holds rows 4*kq + r, column i of every 16x16 tile
+    const int epi = p.epi;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + i;
+        const bool nin = n < p.N;
+        const float bias = (p.bias && nin) ? ldg1(p.bias + n) : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * mt + 4 * kq + r;
+                const bool inb = nin && m < p.M;
+                float v = acc[mt][t][r] + bias;
+                if (epi == EPI_GLU) {
+                    const float g = __shfl_xor(v, 1, 64);               // (value, gate) in adjacent columns / lanes
+                    if (inb && !(i & 1)) stg1(p.C + c_row_off(p, m) + (n >> 1), v * sigmoidf_(g));
+                    continue;
+                }
+                if (!inb) continue;
+                const long long crow = c_row_off(p, m);
+                if (epi == EPI_SILU) v = v * sigmoidf_(v);
+                else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+                else if (epi == EPI_SCALE) v = v * p.alpha;
+                else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
+                else if (epi == EPI_TANH_ADD) {
+                    const int bi = fastdiv(m, p.x_n, p.x_n_magic);
+                    const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
+                    v = tanhf(v + ldg1(p.X + (long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n));
+                }
+                stg1(p.C + crow + n, v);
+            }
+        }
+    }
+}
+
+// XCD-aware work mapping (guide T1): workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
+// private 4 MiB L2.  A wavefront stage multiplies 12 different weight matrices at once (12+ MB): dealt naively,
+// every XCD touches all of them and the operands stream from the Infinity Cache.  Here each (descriptor,
+// column-tile) pair -- i.e. one 64-row slice of one weight matrix -- is pinned to ONE XCD and its M-tiles run
+// there back to back, so a slice is fetched once per launch.  Placement is a speed hint only.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_ns_tab(const GemmP* __restrict__ tab, int n_desc, int ntn, int ntm) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int pair = (slot / ntm) * 8 + xcd;
+    if (pair >= n_desc * ntn) return;
+    const int g = pair / ntn;
+    const GemmP p = tab[g];   // by-value copy: the fields live in SGPRs instead of being re-read inside the K loop
+    gemm_ns_body<MT, NT>(p, pair - g * ntn, slot % ntm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,12 +851,12 @@ __device__ __forceinline__ void layer_norm_body(const LnP& p) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= p.M) return;
-    const float4 v = *reinterpret_cast<const float4*>(p.x + (long long)row * RNNT_D + lane * 4);
+    const float4 v = ldg4(p.x + (long long)row * RNNT_D + lane * 4);
     const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
     const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
     const float rstd = 1.0f / sqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
-    const float4 gg = *reinterpret_cast<const float4*>(p.g + lane * 4);
-    const float4 bb = *reinterpret_cast<const float4*>(p.b + lane * 4);
+    const float4 gg = ldg4(p.g + lane * 4);
+    const float4 bb = ldg4(p.b + lane * 4);
     float4 o;
     o.x = dx * rstd * gg.x + bb.x;
     o.y = dy * rstd * gg.y + bb.y;
@@ -548,10 +865,13 @@ __device__ __forceinline__ void layer_norm_body(const LnP& p) {
     long long off;
     if (p.c_s0 == 0) off = (long long)(row + p.c_r0) * p.c_s1;   // plain rows
     else off = (long long)(row / p.c_n) * p.c_s0 + (long long)((row % p.c_n) + p.c_r0) * p.c_s1;
-    *reinterpret_cast<float4*>(p.y + off + lane * 4) = o;
+    stg4(p.y + off + lane * 4, o);
 }
 __global__ void layer_norm(LnP p) { layer_norm_body(p); }
-__global__ void layer_norm_tab(const LnP* __restrict__ tab) { layer_norm_body(tab[blockIdx.z]); }
+__global__ void layer_norm_tab(const LnP* __restrict__ tab) {
+    const LnP p = tab[blockIdx.z];
+    layer_norm_body(p);
+}
 
 // ------------------------------------------------------------------------------------------------
 // rel_attention: RelPositionMultiHeadedAttention score/softmax/PV (attention.py:400-418,170-177)
@@ -560,6 +880,7 @@ __global__ void layer_norm_tab(const LnP* __restrict__ tab) { layer_norm_body(ta
 //   kc, vc [B][kv_stride rows][256] K / V caches; keys j = 0..T2-1 live at rows kv_start + j
 //   ptab   [5000][256]            pe * W_pos^T for this layer; key j uses row pos_start + j
 //   klen   per-stream number of valid keys (null -> T2 for all; full-context padding mask)
+// (ATT_QB below is the largest query block, NQ = 4.)
 // score(i,j) = ((q_i+u).k_j + (q_i+v).p_j) / 8, softmax over j, out_i = sum_j a_ij v_j.
 // Per 64-key tile: K/P/V rows staged in LDS with coalesced float4 loads; scores with lane = key;
 // online softmax per query row (wave w owns queries w, w+4, w+8, w+12); PV with lane = d.
@@ -579,6 +900,9 @@ struct AttnP {
     int tq, T2, kv_start, pos_start;
     long long kv_stride;
 };
+// NQ = query slots per wave: a workgroup covers 4*NQ queries (wave w owns queries w, w+4, ...).  Streaming chunks
+// have t' = 3..5 new frames, so NQ = 1 or 2 avoids computing 16 query slots for 3 queries.
+template <int NQ>
 __device__ __forceinline__ void rel_attention_body(const AttnP& P) {
     const float* __restrict__ q = P.q;
     const float* __restrict__ kc = P.kc;
@@ -590,29 +914,30 @@ __device__ __forceinline__ void rel_attention_body(const AttnP& P) {
     float* __restrict__ out = P.out;
     const int tq = P.tq, T2 = P.T2, kv_start = P.kv_start, pos_start = P.pos_start;
     const long long kv_stride = P.kv_stride;
-    if ((int)blockIdx.y * ATT_QB >= tq) return;
+    constexpr int QB = 4 * NQ;
+    if ((int)blockIdx.y * QB >= tq) return;
     __shared__ __attribute__((aligned(16))) float Ks[ATT_TK * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Ps[ATT_TK * ATT_LD];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_TK * RNNT_DK];
-    __shared__ __attribute__((aligned(16))) float Qu[ATT_QB * RNNT_DK];
-    __shared__ __attribute__((aligned(16))) float Qv[ATT_QB * RNNT_DK];
-    __shared__ float Pm[ATT_QB * ATT_TK];
+    __shared__ __attribute__((aligned(16))) float Qu[QB * RNNT_DK];
+    __shared__ __attribute__((aligned(16))) float Qv[QB * RNNT_DK];
+    __shared__ float Pm[QB * ATT_TK];
     const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
-    const int q0 = blockIdx.y * ATT_QB;
-    const int nq = min(ATT_QB, tq - q0);
+    const int q0 = blockIdx.y * QB;
+    const int nq = min(QB, tq - q0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nk = klen ? min(klen[b], T2) : T2;
+    const int nk = klen ? min(ldgi(klen + b), T2) : T2;
 
-    for (int e = tid; e < ATT_QB * RNNT_DK; e += 256) {
+    for (int e = tid; e < QB * RNNT_DK; e += 256) {
         const int iq = e >> 6, d = e & 63;
         float qq = 0.f;
-        if (iq < nq) qq = q[((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + d];
-        Qu[e] = qq + bias_u[h * RNNT_DK + d];
-        Qv[e] = qq + bias_v[h * RNNT_DK + d];
+        if (iq < nq) qq = ldg1(q + ((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + d);
+        Qu[e] = qq + ldg1(bias_u + h * RNNT_DK + d);
+        Qv[e] = qq + ldg1(bias_v + h * RNNT_DK + d);
     }
-    float mrun[4], lrun[4], o[4];
+    float mrun[NQ], lrun[NQ], o[NQ];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NQ; ++s) {
         mrun[s] = -INFINITY;
         lrun[s] = 0.f;
         o[s] = 0.f;
@@ -629,9 +954,9 @@ __device__ __forceinline__ void rel_attention_body(const AttnP& P) {
             const int j = j0 + r;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), pv = kv, vv = kv;
             if (j < nk) {
-                kv = *reinterpret_cast<const float4*>(kbase + (long long)j * RNNT_D + c4 * 4);
-                pv = *reinterpret_cast<const float4*>(pbase + (long long)j * RNNT_D + c4 * 4);
-                vv = *reinterpret_cast<const float4*>(vbase + (long long)j * RNNT_D + c4 * 4);
+                kv = ldg4(kbase + (long long)j * RNNT_D + c4 * 4);
+                pv = ldg4(pbase + (long long)j * RNNT_D + c4 * 4);
+                vv = ldg4(vbase + (long long)j * RNNT_D + c4 * 4);
             }
             *reinterpret_cast<float4*>(&Ks[r * ATT_LD + c4 * 4]) = kv;
             *reinterpret_cast<float4*>(&Ps[r * ATT_LD + c4 * 4]) = pv;
@@ -639,13 +964,15 @@ __device__ __forceinline__ void rel_attention_body(const AttnP& P) {
         }
         __syncthreads();
         // scores: lane = key
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        float s[NQ];
+#pragma unroll
+        for (int sI = 0; sI < NQ; ++sI) s[sI] = 0.f;
 #pragma unroll 4
         for (int dc = 0; dc < 16; ++dc) {
             const float4 k4 = *reinterpret_cast<const float4*>(&Ks[lane * ATT_LD + dc * 4]);
             const float4 p4 = *reinterpret_cast<const float4*>(&Ps[lane * ATT_LD + dc * 4]);
 #pragma unroll
-            for (int sI = 0; sI < 4; ++sI) {
+            for (int sI = 0; sI < NQ; ++sI) {
                 const int iq = wave + 4 * sI;
                 const float4 u4 = *reinterpret_cast<const float4*>(&Qu[iq * RNNT_DK + dc * 4]);
                 const float4 v4 = *reinterpret_cast<const float4*>(&Qv[iq * RNNT_DK + dc * 4]);
@@ -662,9 +989,9 @@ __device__ __forceinline__ void rel_attention_body(const AttnP& P) {
             }
         }
         const bool valid = (j0 + lane) < nk;
-        float alpha[4];
+        float alpha[NQ];
 #pragma unroll
-        for (int sI = 0; sI < 4; ++sI) {
+        for (int sI = 0; sI < NQ; ++sI) {
             const float sc = valid ? s[sI] * 0.125f : -INFINITY;
             const float mnew = fmaxf(mrun[sI], wave_max(sc));
             const float pe_ = valid ? expf(sc - mnew) : 0.f;
@@ -676,22 +1003,27 @@ __device__ __forceinline__ void rel_attention_body(const AttnP& P) {
         __syncthreads();   // Pm visible (uniform trip count: nk is the same for the whole workgroup)
         // PV: lane = d
 #pragma unroll
-        for (int sI = 0; sI < 4; ++sI) o[sI] *= alpha[sI];
+        for (int sI = 0; sI < NQ; ++sI) o[sI] *= alpha[sI];
         const int jn = min(ATT_TK, nk - j0);
         for (int j = 0; j < jn; ++j) {
             const float vj = Vs[j * RNNT_DK + lane];
 #pragma unroll
-            for (int sI = 0; sI < 4; ++sI) o[sI] = fmaf(Pm[(wave + 4 * sI) * ATT_TK + j], vj, o[sI]);
+            for (int sI = 0; sI < NQ; ++sI) o[sI] = fmaf(Pm[(wave + 4 * sI) * ATT_TK + j], vj, o[sI]);
         }
     }
 #pragma unroll
-    for (int sI = 0; sI < 4; ++sI) {
+    for (int sI = 0; sI < NQ; ++sI) {
         const int iq = wave + 4 * sI;
-        if (iq < nq) out[((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + lane] = o[sI] / lrun[sI];
+        if (iq < nq) stg1(out + ((long long)b * tq + q0 + iq) * RNNT_D + h * RNNT_DK + lane, o[sI] / lrun[sI]);
     }
 }
-__global__ __launch_bounds__(256) void rel_attention(AttnP p) { rel_attention_body(p); }
-__global__ __launch_bounds__(256) void rel_attention_tab(const AttnP* __restrict__ tab) { rel_attention_body(tab[blockIdx.z]); }
+template <int NQ>
+__global__ __launch_bounds__(256) void rel_attention(AttnP p) { rel_attention_body<NQ>(p); }
+template <int NQ>
+__global__ __launch_bounds__(256) void rel_attention_tab(const AttnP* __restrict__ tab) {
+    const AttnP p = tab[blockIdx.z];
+    rel_attention_body<NQ>(p);
+}
 
 // ------------------------------------------------------------------------------------------------
 // dwconv_bn_silu: causal depthwise conv k=31 + BatchNorm(eval) + SiLU over the post-GLU ring
@@ -728,21 +1060,24 @@ __device__ __forceinline__ void dwconv_body(const DwP& P) {
         const int m = (int)(id >> 8);
         const int b = m / tq, r = m % tq;
         const float* gb = g + (long long)b * cap * RNNT_D + c;
-        float acc = bdw[c];
+        float acc = ldg1(bdw + c);
         int ridx = (pos + r - RNNT_LORDER + cap * 64) % cap;   // ring row of the oldest tap (operand kept positive)
 #pragma unroll
         for (int k = 0; k < RNNT_KDW; ++k) {
-            acc = fmaf(wdw_t[k * RNNT_D + c], gb[(long long)ridx * RNNT_D], acc);
+            acc = fmaf(ldg1(wdw_t + k * RNNT_D + c), ldg1(gb + (long long)ridx * RNNT_D), acc);
             ridx = ridx + 1 == cap ? 0 : ridx + 1;
         }
-        float v = acc * bn_s[c] + bn_t[c];
+        float v = acc * ldg1(bn_s + c) + ldg1(bn_t + c);
         v = v * sigmoidf_(v);
-        out[id] = v;
-        if (xring) xring[((long long)b * cap + (pos + r) % cap) * RNNT_D + c] = xres[id];
+        stg1(out + id, v);
+        if (xring) stg1(xring + ((long long)b * cap + (pos + r) % cap) * RNNT_D + c, ldg1(xres + id));
     }
 }
 __global__ void dwconv_bn_silu(DwP p) { dwconv_body(p); }
-__global__ void dwconv_bn_silu_tab(const DwP* __restrict__ tab) { dwconv_body(tab[blockIdx.z]); }
+__global__ void dwconv_bn_silu_tab(const DwP* __restrict__ tab) {
+    const DwP p = tab[blockIdx.z];
+    dwconv_body(p);
+}
 
 // fill the 30 left-context rows of a fresh stream: g ring <- GLU(b_pw1) (zero input through the
 // biased pointwise conv, convolution.py:122-124,138-139), xin ring <- 0.
@@ -758,12 +1093,13 @@ __global__ void conv_ring_init(float* __restrict__ g, float* __restrict__ xring,
 }
 
 // ------------------------------------------------------------------------------------------------
-// greedy_update: one workgroup (one wave) per stream.  argmax over the vocabulary (first max index
-// on ties, like torch.argmax) then the per-stream state machine of
+// greedy_decide: one thread per stream applies the argmax of the previous evaluation (packed key written by the
+// EPI_ARGMAX epilogue of joint.ffn_out) to the per-stream RNN-T greedy state machine of
 // _decode_chunk_streaming_logic (online_rnnt_model.py:193-220):
 //   blank      -> next frame, symbol counter reset
-//   non-blank  -> emit, commit LSTM state (h,c <- h',c'), token <- k; after n_steps symbols on one
-//                 frame move to the next frame.
+//   non-blank  -> emit, token <- k, the candidate LSTM state becomes the committed one (sel ^= 1: the two
+//                 state buffers swap roles, no copy); after n_steps symbols on one frame move to the next frame.
+// key == 0 means "no evaluation pending" (idle stream, or already applied).
 // ------------------------------------------------------------------------------------------------
 struct GreedyState {
     int* tok;        // [B] predictor input token
@@ -771,62 +1107,46 @@ struct GreedyState {
     int* nsym;       // [B] symbols emitted on the current frame
     int* count;      // [B] tokens emitted so far
     int* tokens;     // [B][max_tokens]
-    int* n_active;   // [1] streams with frames left
-    float* h;        // [B][256] committed
-    float* c;
-    const float* h2; // [B][256] candidate
-    const float* c2;
+    int* sel;        // [B] which LSTM state buffer is committed
+    unsigned long long* key;   // [B]
+    int* misc;       // [0] streams with frames left (greedy_decide with count != 0), [1] beam rows active, [2] decodable frames
 };
 
-__global__ __launch_bounds__(64) void greedy_update(const float* __restrict__ logits, int ldl, int vocab, int blank, int n_steps,
-                                                  int n_frames, int max_tokens, GreedyState st) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    int f = st.fidx[b];
-    if (f >= n_frames) return;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int v = lane; v < vocab; v += 64) {
-        const float x = logits[(long long)b * ldl + v];
-        if (x > best) {
-            best = x;
-            bi = v;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) {
-            best = ob;
-            bi = oi;
-        }
-    }
-    if (bi == blank) {
-        f += 1;
-        if (lane == 0) {
-            st.fidx[b] = f;
-            st.nsym[b] = 0;
-            if (f >= n_frames) atomicSub(st.n_active, 1);
-        }
-    } else {
-        for (int d = lane; d < RNNT_D; d += 64) {
-            st.h[b * RNNT_D + d] = st.h2[b * RNNT_D + d];
-            st.c[b * RNNT_D + d] = st.c2[b * RNNT_D + d];
-        }
-        if (lane == 0) {
-            const int cnt = st.count[b];
-            if (cnt < max_tokens) st.tokens[(long long)b * max_tokens + cnt] = bi;
-            st.count[b] = cnt + 1;
-            st.tok[b] = bi;
-            const int ns = st.nsym[b] + 1;
-            if (ns >= n_steps) {
+__global__ __launch_bounds__(64) void greedy_decide(int B, int blank, int n_steps, int max_tokens, int do_count, GreedyState st) {
+    const int n_frames = st.misc[2];
+    int act = 0;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const unsigned long long k64 = st.key[b];
+        int f = st.fidx[b];
+        if (k64 != 0ull) {
+            st.key[b] = 0ull;
+            const int k = (int)(0xFFFFFFFFu - (unsigned)(k64 & 0xFFFFFFFFull));
+            if (k == blank) {
+                f += 1;
+                st.fidx[b] = f;
                 st.nsym[b] = 0;
-                st.fidx[b] = f + 1;
-                if (f + 1 >= n_frames) atomicSub(st.n_active, 1);
             } else {
-                st.nsym[b] = ns;
+                const int cnt = st.count[b];
+                if (cnt < max_tokens) st.tokens[(long long)b * max_tokens + cnt] = k;
+                st.count[b] = cnt + 1;
+                st.tok[b] = k;
+                st.sel[b] ^= 1;
+                const int ns = st.nsym[b] + 1;
+                if (ns >= n_steps) {
+                    st.nsym[b] = 0;
+                    f += 1;
+                    st.fidx[b] = f;
+                } else {
+                    st.nsym[b] = ns;
+                }
             }
         }
+        act += f < n_frames ? 1 : 0;
+    }
+    if (do_count) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) act += __shfl_xor(act, o, 64);
+        if (threadIdx.x == 0) st.misc[0] = act;
     }
 }
 

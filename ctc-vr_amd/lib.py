@@ -26,7 +26,7 @@ SIGNATURES = {
     "rnnt_finalize_weights": (c_i32, [c_vp, c_i32, c_vp]),
     "rnnt_streams_reset": (c_i32, [c_vp, c_i32, c_vp]),
     "rnnt_encoder_chunk": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32p, c_vp]),
-    "rnnt_encoder_chunks": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32p, c_vp]),
+    "rnnt_encoder_chunks": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32p, c_vp]),
     "rnnt_greedy_decode": (c_i32, [c_vp, c_vp]),
     "rnnt_get_tokens": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "rnnt_frames_consume": (c_i32, [c_vp, c_vp]),
@@ -141,11 +141,11 @@ class RnntEngine:
                   "rnnt_encoder_chunk")
         return t.value
 
-    def encoder_chunks(self, fbank_ptr, total_frames, starts, lens, offsets, required, stream=None):
+    def encoder_chunks(self, fbank_ptr, total_frames, starts, lens, offsets, required, stream=None, greedy=False):
         a, b, c, d = (np.ascontiguousarray(v, np.int32) for v in (starts, lens, offsets, required))
         t = c_i32(0)
         self._chk(self.lib.rnnt_encoder_chunks(self.ctx, fbank_ptr, total_frames, len(a), _np_ptr(a), _np_ptr(b), _np_ptr(c), _np_ptr(d),
-                                               ctypes.byref(t), stream), "rnnt_encoder_chunks")
+                                               1 if greedy else 0, ctypes.byref(t), stream), "rnnt_encoder_chunks")
         return t.value
 
     def greedy_decode(self, stream=None):

@@ -376,9 +376,8 @@ class StreamingBatch:
                     offs.append(o)
                     o += (b - a) // 4
             s = _stream_ptr()
-            self.engine.encoder_chunks(audios.data_ptr(), T, starts, lens, offs, offs, s)
+            self.engine.encoder_chunks(audios.data_ptr(), T, starts, lens, offs, offs, s, greedy=True)
             self.offset = o
-            self.engine.greedy_decode(s)
             self.engine.frames_consume(s)
             return self.engine.tokens(s)
         for (a, b) in chunk_plan(T, chunk_frames):

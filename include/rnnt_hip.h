@@ -94,11 +94,13 @@ int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t chunk_fram
 /* replaces the whole chunk loop around forward_chunk (online_rnnt_decode.py:87-117, or streaming_inference,
  * model/online_rnnt_model.py:311-342) for utterances that are fully available: chunk c of every stream covers fbank
  * frames [chunk_start[c], chunk_start[c]+chunk_len[c]) and is encoded with (offsets[c], required[c]) exactly as
- * n_chunks calls of rnnt_encoder_chunk would (bit-identical results), but scheduled as a wavefront over
- * (chunk, layer) with batched subsampling.  fbank_dev [n_streams, total_frames, 80]; host int arrays. */
+ * n_chunks calls of rnnt_encoder_chunk would (same float32 arithmetic up to summation order), scheduled as a wavefront over
+ * (chunk, layer) with batched subsampling.  fbank_dev [n_streams, total_frames, 80]; host int arrays.
+ * greedy != 0: the greedy decode of rnnt_greedy_decode runs concurrently on an internal stream, consuming each
+ * chunk's frames as soon as they exist; the call then returns with all frames decoded (synchronises). */
 int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_frames, int32_t n_chunks,
                         const int32_t* chunk_start, const int32_t* chunk_len, const int32_t* offsets,
-                        const int32_t* required, int32_t* frames_out, void* stream);
+                        const int32_t* required, int32_t greedy, int32_t* frames_out, void* stream);
 
 /* replaces the greedy loops of _decode_chunk_streaming_logic (model/online_rnnt_model.py:183-222)
  * over every buffered encoder frame not yet decoded, all streams in parallel, state carried in

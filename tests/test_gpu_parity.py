@@ -209,9 +209,10 @@ def test_batched_streams_equal_single_stream_reference(np_state_dict):
             assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (per_chunk, i)
 
 
-def test_wavefront_encoder_is_bit_identical(np_state_dict):
-    """rnnt_encoder_chunks (wavefront over chunk x layer, batched subsampling) vs chunk-by-chunk
-    rnnt_encoder_chunk: encoder frames and K/V cache bit-identical, tokens equal the reference."""
+def test_wavefront_encoder_matches_chunk_by_chunk(np_state_dict):
+    """rnnt_encoder_chunks (wavefront over chunk x layer, batched subsampling, LDS-tiled grouped GEMMs) vs
+    chunk-by-chunk rnnt_encoder_chunk (split-K GEMMs): same arithmetic with a different K summation order, so
+    encoder frames / caches agree to float32 rounding (1e-4 observed ~1e-6) and the tokens equal the reference."""
     from ctc_vr_amd.online_rnnt_model import StreamingBatch
     g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
     syn = torch.from_numpy(T.synth_fbank(2, 1000))
@@ -232,9 +233,9 @@ def test_wavefront_encoder_is_bit_identical(np_state_dict):
     plan = T.chunk_plan(1000, 16)
     offs = [4 * i for i in range(len(plan))]
     sb.engine.encoder_chunks(x.data_ptr(), 1000, [a for a, _ in plan], [b - a for a, b in plan], offs, offs, s)
-    assert np.array_equal(sb.engine.enc_frames(s), enc_seq)
-    assert np.array_equal(sb.engine.att_cache(1, s), att_seq)
-    assert np.array_equal(sb.engine.cnn_cache(1, s), cnn_seq)
+    assert maxdiff(sb.engine.enc_frames(s), enc_seq) < 1e-4
+    assert maxdiff(sb.engine.att_cache(1, s), att_seq) < 1e-4
+    assert maxdiff(sb.engine.cnn_cache(1, s), cnn_seq) < 1e-4
     assert maxdiff(enc_seq[0], g0["enc_out"]) < LOGIT_TOL
 
 

@@ -20,7 +20,7 @@ static GemmP plain(const float* A, int lda, const float* W, int ldw, const float
 template <int WK, int NT> void launch16(hipStream_t s, const GemmP& g) {
     GemmBatch gb; memset(&gb, 0, sizeof(gb)); gb.g[0] = g; gb.g[0].a_plain = 1; gb.g[0].c_plain = 1;
     dim3 grid((g.N + 16 * NT - 1) / (16 * NT), (g.M + 15) / 16, 1);
-    hipLaunchKernelGGL((gemm16<WK, NT>), grid, dim3(64 * WK), 0, s, gb);
+    hipLaunchKernelGGL((gemm16<WK, 1, NT>), grid, dim3(64 * WK), 0, s, gb);
 }
 template <int WK> void launch(hipStream_t s, const GemmP& g) {
     GemmBatch gb; memset(&gb, 0, sizeof(gb)); gb.g[0] = g;
