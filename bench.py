@@ -7,8 +7,10 @@
 
 One "step" = one pass of the hot path over one batch: 64 independent 10 s streams per GPU
 (synthetic 80-dim fbank already resident in HBM), 16-frame chunks with online_rnnt_decode.py's
-slicing/offset rules (BASELINE.json configs[1]), chunked Conformer encoder + greedy RNN-T decode, tokens
-copied back to the host after every chunk (per-chunk mode, the reference script's behaviour).  Streams
+slicing/offset rules (BASELINE.json configs[1]), chunked Conformer encoder + greedy RNN-T decode.  Default mode
+"pipelined": the whole chunk plan goes to rnnt_encoder_chunks (wavefront over chunk x layer, decode overlapped on a
+second stream), tokens copied back once per utterance batch -- the same tokens as the per-chunk API, whose
+throughput (tokens to the host after EVERY chunk, the reference script's loop) is reported beside it.  Streams
 shard across ranks with no data-path collective (weak scaling); weights are broadcast once over RCCL.
 Prints ONE JSON line on rank 0.
 """
@@ -74,11 +76,14 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="streams per GPU")
     ap.add_argument("--frames", type=int, default=1000, help="fbank frames per stream (10 ms each)")
     ap.add_argument("--chunk", type=int, default=16, help="fbank frames per chunk (online_rnnt_decode.py semantics)")
-    ap.add_argument("--mode", default="per_chunk", choices=["per_chunk", "deferred", "pipelined"],
+    ap.add_argument("--mode", default="pipelined", choices=["per_chunk", "deferred", "pipelined"],
                     help="per_chunk: tokens returned to the host after every chunk; deferred: one decode after the last chunk; "
                          "pipelined: whole chunk plan in one rnnt_encoder_chunks call (wavefront over chunk x layer), one decode")
     ap.add_argument("--site", default="conv2", choices=sorted(TAGS), help="launch site timed for the roofline object")
     ap.add_argument("--cpu-streams", type=int, default=8, help="streams of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="torch threads for the CPU oracle (8 = the reference survey's setting; "
+                                                                "B=1 ops are tiny, more threads are slower)")
+    ap.add_argument("--also-per-chunk", type=int, default=1, help="also time the per-chunk API mode (reported as extra fields)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -161,9 +166,21 @@ def main():
         roofline["launches_timed"] = int(site_launches)
         roofline["share_of_step"] = round(site_ms * 1e-3 / elapsed, 4)
 
+    per_chunk_extra = None
+    if args.also_per_chunk and args.mode != "per_chunk" and world == 1:
+        sb.decode_script(x, args.chunk, per_chunk_decode=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks_pc = sb.decode_script(x, args.chunk, per_chunk_decode=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        per_chunk_extra = {"value": round(B * args.frames / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tokens_equal_pipelined": toks_pc == toks,
+                           "note": "tokens copied to the host after every chunk (online_rnnt_decode.py loop, process_single_chunk API)"}
+
     cpu = None
     if not args.no_cpu and world == 1:
         from oracle import rnnt_oracle as O   # CPU baseline leg ONLY (checker / baseline, never the product path)
+        torch.set_num_threads(args.cpu_threads)
         sd_t = O.to_torch_sd(sd_np)
         xc = x[:args.cpu_streams].cpu()
         t0 = time.perf_counter()
@@ -202,6 +219,7 @@ def main():
         "weight_broadcast_ms": round(bcast_ms, 3),
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "per_chunk_api": per_chunk_extra,
     }
     print(json.dumps(out))
     if world > 1:

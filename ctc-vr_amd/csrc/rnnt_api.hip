@@ -90,7 +90,7 @@ struct rnnt_ctx {
     std::vector<DecGraph> dec_graphs;          // K greedy steps captured once per (n_streams, K)
     bool capturing = false;
     int use_graphs = 1;
-    std::vector<hipEvent_t> wf_ev;
+    std::vector<hipEvent_t> wf_ev, wf_evd;
     // optional per-kernel-site timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_tag = -1;
     std::vector<hipEvent_t> prof_ev;
@@ -402,7 +402,7 @@ int launch_gemm_tab(rnnt_ctx* ctx, hipStream_t s, const GemmP* tab_dev, int n, i
 //   joint out       logits = z * W_out^T + b, argmax fused into the epilogue (packed atomicMax; online_rnnt_model.py:212)
 // Streams without frames idle.
 GreedyState greedy_state(rnnt_ctx* ctx) {
-    return GreedyState{ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->sel, ctx->key, ctx->n_active};
+    return GreedyState{ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->sel, ctx->key, ctx->n_active, ctx->pinned + 8};
 }
 
 int greedy_steps_raw(rnnt_ctx* ctx, hipStream_t s, int n) {
@@ -574,6 +574,7 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->wf_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->wf_evd) (void)hipEventDestroy(e);
     if (ctx->dec_stream) (void)hipStreamDestroy(ctx->dec_stream);
     for (auto& g : ctx->dec_graphs) (void)hipGraphExecDestroy(g.exec);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
@@ -1019,6 +1020,12 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->wf_ev.push_back(e);
         }
+        while ((int)ctx->wf_evd.size() < C) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->wf_evd.push_back(e);
+        }
+        ctx->pinned[8] = 0;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s));          // everything enqueued before this call (reset, earlier decode)
         HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[C], 0));
     }
@@ -1067,9 +1074,20 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         if (greedy) {
             HIPCHK(hipEventRecord(ctx->wf_ev[c], s));
             HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c], 0));
+            // Step budget of this chunk: its frames + a little slack + whatever backlog the slowest stream has built up
+            // ("runaway" streams emit up to n_steps symbols per frame).  The backlog is read from pinned memory that
+            // greedy_decide updates every step; to keep it only a few chunks stale the host stays <= LAG chunks ahead.
             static const int slack = getenv("RNNT_DEC_SLACK") ? atoi(getenv("RNNT_DEC_SLACK")) : 8;
-            const int budget = ci[c].tq + slack;   // frames + typical symbols; stragglers are finished by the drain below
+            static const int lag = getenv("RNNT_DEC_LAG") ? atoi(getenv("RNNT_DEC_LAG")) : 0;   // 0 = static budgets (feedback overshoots: stale backlog)
+            int backlog = 0;
+            if (lag > 0 && c >= lag) {
+                HIPCHK(hipEventSynchronize(ctx->wf_evd[c - lag]));
+                backlog = *(volatile int*)(ctx->pinned + 8);
+            }
+            int budget = ci[c].tq + slack + (backlog > 0 ? (backlog * 6 < 64 ? backlog * 6 : 64) : 0);
+            budget = (budget + 3) / 4 * 4;   // few distinct graph sizes
             if ((rc = greedy_steps(ctx, s2, budget, ci[c].fpos + ci[c].tq))) return rc;
+            HIPCHK(hipEventRecord(ctx->wf_evd[c], s2));
             dec_steps += budget;
             if (timing) { double t = now(); t_dec += t - tl; tl = t; }
         }

@@ -1110,11 +1110,12 @@ struct GreedyState {
     int* sel;        // [B] which LSTM state buffer is committed
     unsigned long long* key;   // [B]
     int* misc;       // [0] streams with frames left (greedy_decide with count != 0), [1] beam rows active, [2] decodable frames
+    int* host_backlog;   // host-mapped pinned int: max over streams of (decodable frames - current frame), written every call
 };
 
 __global__ __launch_bounds__(64) void greedy_decide(int B, int blank, int n_steps, int max_tokens, int do_count, GreedyState st) {
     const int n_frames = st.misc[2];
-    int act = 0;
+    int act = 0, behind = 0;
     for (int b = threadIdx.x; b < B; b += 64) {
         const unsigned long long k64 = st.key[b];
         int f = st.fidx[b];
@@ -1142,7 +1143,11 @@ __global__ __launch_bounds__(64) void greedy_decide(int B, int blank, int n_step
             }
         }
         act += f < n_frames ? 1 : 0;
+        behind = max(behind, n_frames - f);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) behind = max(behind, __shfl_xor(behind, o, 64));
+    if (threadIdx.x == 0 && st.host_backlog) *st.host_backlog = behind;   // stale-tolerant feedback for the host's step budgets
     if (do_count) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) act += __shfl_xor(act, o, 64);
