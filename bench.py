@@ -68,6 +68,61 @@ def site_flops_bytes(site, B, plan):
     return fl, by, n
 
 
+def side_workload(args, sd_np, dev, world, rank):
+    """BASELINE configs[2] (beam 4) and configs[4] (full-context encoder): secondary lines, same JSON shape."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    from ctc_vr_amd.lib import RnntEngine
+    assert world == 1
+    if args.workload == "beam":
+        B = args.batch
+        plan = T.chunk_plan(args.frames, args.chunk)
+        enc_frames = sum(sub_len(b - a) for a, b in plan)
+        sb = StreamingBatch(sd_np, B, max_chunk_frames=max(b - a for a, b in plan), max_cache_frames=enc_frames + 8, max_enc_frames=16,
+                            max_tokens=16, device=0, max_beam=4)
+        x = torch.from_numpy(T.synth_fbank(B, args.frames, seed=1234)).to(dev).contiguous()
+        for _ in range(args.warmup):
+            sb.beam_script(x, args.chunk, 4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            beams = sb.beam_script(x, args.chunk, 4)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out = {"metric": "audio-frames/sec, streaming RNN-T beam search (beam 4)", "value": round(B * args.frames * args.steps / el, 1),
+               "unit": "audio-frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"configs[2]: batch={B} beam_search beam=4, streaming chunk={args.chunk}, per-chunk API; hypothesis "
+                                      f"bookkeeping on the host in Python (reference-exact order), device extension chains",
+                          "best_tokens_stream0": len(max(beams[0], key=lambda h: h.log_prob).tokens)}}
+        print(json.dumps(out))
+        return
+    # full context: B x 30 s, decoding_chunk_size = -1
+    B, Tn = 32, 3000
+    eng = RnntEngine(max_streams=B, max_chunk_frames=Tn, max_cache_frames=760, max_enc_frames=8, vocab_size=T.VOCAB, blank_id=T.BLANK, device=0)
+    eng.load_state_dict(sd_np)
+    x = torch.from_numpy(T.synth_fbank(B, Tn, seed=1234)).to(dev).contiguous()
+    tq = sub_len(Tn)
+    out_t = torch.empty(B, tq, 256, device=dev)
+    lens = np.full(B, Tn, np.int32)
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        eng.encoder_full(x.data_ptr(), lens, B, Tn, out_t.data_ptr(), s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.encoder_full(x.data_ptr(), lens, B, Tn, out_t.data_ptr(), s)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    flops = B * 2.0 * (tq * (11.2e6 + 1.25e6 + 0.18e6 + 18.183168e6 + 9216.0 * tq))   # SURVEY.md §8d config 5
+    out = {"metric": "audio-frames/sec, full-context Conformer encoder", "value": round(B * Tn * args.steps / el, 1), "unit": "audio-frames/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"configs[4]: full-context encoder, batch={B} x 30 s (decoding_chunk_size=-1), {tq} frames per utterance"},
+           "roofline": {"bound": "mfma", "kernel": "whole encoder pass", "achieved": round(flops * args.steps / el / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(flops * args.steps / el / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +140,8 @@ def main():
                                                                 "B=1 ops are tiny, more threads are slower)")
     ap.add_argument("--also-per-chunk", type=int, default=1, help="also time the per-chunk API mode (reported as extra fields)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "full_context"],
+                    help="greedy = BASELINE configs[1] (default); beam = configs[2] (beam 4, per-chunk); full_context = configs[4]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,6 +164,8 @@ def main():
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
 
+    if args.workload != "greedy":
+        return side_workload(args, sd_np, dev, world, rank)
     from ctc_vr_amd.online_rnnt_model import StreamingBatch
     B = args.batch
     plan = T.chunk_plan(args.frames, args.chunk)

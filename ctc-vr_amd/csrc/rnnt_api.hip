@@ -85,6 +85,7 @@ struct rnnt_ctx {
     GemmP* wf_gtab = nullptr; AttnP* wf_atab = nullptr; DwP* wf_dtab = nullptr; LnP* wf_ltab = nullptr;
     size_t wf_gcap = 0, wf_acap = 0, wf_dcap = 0, wf_lcap = 0;
     hipStream_t dec_stream = nullptr;          // decode runs here while the encoder wavefront runs on the caller's stream
+    hipStream_t enc_stream = nullptr;          // experiment (RNNT_DEC_CUS): encoder on the complementary CU mask
     hipStream_t cap_stream = nullptr;          // stream-capture scratch stream
     struct DecGraph { int n_streams, k; hipGraphExec_t exec; };
     std::vector<DecGraph> dec_graphs;          // K greedy steps captured once per (n_streams, K)
@@ -166,23 +167,30 @@ GemmP plain_gemm(const float* A, int lda, const float* W, int ldw, const float* 
     return p;
 }
 
-inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
+// q = umulhi(n, magic) >> shift, exact for 0 <= n < 2^31 (round-up method: magic = ceil(2^(32+shift) / d))
+inline void div_magic(int d, unsigned& magic, int& shift) {
+    if (d <= 1) { magic = 0; shift = 0; return; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;          // l = ceil(log2 d)
+    shift = l - 1;
+    const unsigned long long num = 1ull << (32 + shift);
+    magic = (unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d);
+}
 
 // fast-path flags and division magics of one GEMM descriptor (gemm16's a_row_off / c_row_off)
 int prepare_gemm(rnnt_ctx* ctx, GemmP& g) {
     g.a_plain = (g.a_n1 == BIG && g.a_n2 == BIG && g.a_seg == BIG) ? 1 : 0;
     g.c_plain = (g.c_n == BIG && g.c_r0 == 0) ? 1 : 0;
-    auto ok = [&](long long nmax, int d) { return d == BIG || nmax * (long long)d < (1ll << 32); };
-    if (!ok(g.M, g.a_n1) || !ok(g.M, g.a_n2) || !ok(g.K, g.a_seg) || !ok(g.M, g.c_n) || !ok(g.M, g.x_n))
-        return fail(ctx, RNNT_ERR_SHAPE, "gemm index range too large for the division magics");
+    if ((long long)g.M >= (1ll << 31) || (long long)g.K >= (1ll << 31)) return fail(ctx, RNNT_ERR_SHAPE, "gemm index range too large");
     if (!g.a_plain) {
         if (g.a_n1 == BIG) g.a_n1 = g.M > 0 ? g.M + 1 : 1;   // quotient 0, remainder m
         if (g.a_n2 == BIG) g.a_n2 = g.M > 0 ? g.M + 1 : 1;
         if (g.a_seg == BIG) { g.a_seg = g.K + 1; g.a_seg_stride = 0; }
     }
     if (!g.c_plain && g.c_n == BIG) g.c_n = g.M > 0 ? g.M + 1 : 1;
-    g.a_n1_magic = div_magic(g.a_n1); g.a_n2_magic = div_magic(g.a_n2); g.a_seg_magic = div_magic(g.a_seg);
-    g.c_n_magic = div_magic(g.c_n); g.x_n_magic = div_magic(g.x_n);
+    div_magic(g.a_n1, g.a_n1_magic, g.a_n1_shift); div_magic(g.a_n2, g.a_n2_magic, g.a_n2_shift);
+    div_magic(g.a_seg, g.a_seg_magic, g.a_seg_shift); div_magic(g.c_n, g.c_n_magic, g.c_n_shift);
+    div_magic(g.x_n, g.x_n_magic, g.x_n_shift);
     return RNNT_OK;
 }
 
@@ -211,6 +219,19 @@ int launch_gemm(rnnt_ctx* ctx, hipStream_t s, int wk, const GemmP* gs, int ng, i
         const int K = gs[0].K;
         for (int i = 0; i < ng; ++i)
             if (gs[i].K != K) return fail(ctx, RNNT_ERR_SHAPE, "grouped gemm needs one K");
+        const int epi0 = gs[0].epi;
+        if (maxM >= 1024 && K % 32 == 0 && epi0 != EPI_LSTM && epi0 != EPI_ARGMAX) {
+            // large M (full-context encoder, batched subsampling, joint lattice): LDS-tiled kernel, no split-K
+            if (maxN >= 512) {
+                dim3 grid((maxN + 63) / 64, (maxM + 63) / 64, ng);
+                hipLaunchKernelGGL((gemm_ns<2, 2>), grid, dim3(256), 0, s, gb);
+            } else {
+                dim3 grid((maxN + 63) / 64, (maxM + 31) / 32, ng);
+                hipLaunchKernelGGL((gemm_ns<1, 2>), grid, dim3(256), 0, s, gb);
+            }
+            LAUNCHCHK("gemm_ns");
+            return RNNT_OK;
+        }
         const bool wide = maxN >= 512 && gs[0].epi != EPI_LSTM ? true : (maxN >= 512);
         const int wkk = K >= 1024 ? 8 : 4;
         if (K % (wkk * 16) != 0) return fail(ctx, RNNT_ERR_SHAPE, "gemm16 K=%d not divisible by %d", K, wkk * 16);
@@ -353,7 +374,17 @@ int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T
     g.a_n1 = tq * RNNT_FSUB; g.a_n2 = RNNT_FSUB;
     g.a_s0 = (long long)t1 * RNNT_F1 * D; g.a_s1 = 2LL * RNNT_F1 * D; g.a_s2 = 2LL * D;
     g.a_seg = 768; g.a_seg_stride = (long long)RNNT_F1 * D;
-    if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;
+    static const int conv2_lds = getenv("RNNT_CONV2_LDS") ? atoi(getenv("RNNT_CONV2_LDS")) : 1;
+    if (conv2_lds && g.M >= 2048) {   // big M: LDS-tiled 64x64 tiles (full-line operand staging); N = 256 -> 4 column tiles
+        ProfScope prof(ctx, s, TAG_CONV2);
+        GemmBatch gb;
+        memset(&gb, 0, sizeof(gb));
+        gb.g[0] = g;
+        if ((rc = prepare_gemm(ctx, gb.g[0]))) return rc;
+        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, 1);
+        hipLaunchKernelGGL((gemm_ns<2, 2>), grid, dim3(256), 0, s, gb);
+        LAUNCHCHK("gemm_ns");
+    } else if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;
     // Linear(4864 -> 256) * sqrt(256); y2 is [VB*t', f*256 + c] (weight columns permuted to match)
     GemmP go = plain_gemm(y2, RNNT_FSUB * D, ctx->emb_w, RNNT_FSUB * D, ctx->emb_b, xout, D, VB * tq, D, RNNT_FSUB * D, EPI_SCALE, 16.0f);
     if ((rc = launch_gemm(ctx, s, 0, &go, 1, TAG_EMBED))) return rc;
@@ -478,8 +509,9 @@ int greedy_drain(rnnt_ctx* ctx, hipStream_t s, int n_frames, int done_steps) {
         HIPCHK(hipStreamSynchronize(s));
         if (ctx->pinned[0] <= 0) break;
         if (done_steps > max_steps) return fail(ctx, RNNT_ERR_STATE, "greedy decode did not terminate");
-        if ((rc = greedy_steps(ctx, s, 4, n_frames))) return rc;
-        done_steps += 4;
+        static const int dstep = getenv("RNNT_DRAIN_STEPS") ? atoi(getenv("RNNT_DRAIN_STEPS")) : 4;
+        if ((rc = greedy_steps(ctx, s, dstep, n_frames))) return rc;
+        done_steps += dstep;
     }
     return RNNT_OK;
 }
@@ -578,6 +610,7 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     if (ctx->dec_stream) (void)hipStreamDestroy(ctx->dec_stream);
     for (auto& g : ctx->dec_graphs) (void)hipGraphExecDestroy(g.exec);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    if (ctx->enc_stream) (void)hipStreamDestroy(ctx->enc_stream);
     void* wf[] = {ctx->wf_x, ctx->wf_h, ctx->wf_q, ctx->wf_a, ctx->wf_d, ctx->wf_y1, ctx->wf_y2, ctx->wf_starts, ctx->wf_gtab, ctx->wf_atab,
                   ctx->wf_dtab, ctx->wf_ltab};
     for (void* q : wf)
@@ -997,19 +1030,22 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     static const int gTag[8] = {TAG_FFN1, TAG_FFN2, TAG_QKV, TAG_ATTN_OUT, TAG_PW1, TAG_PW2, TAG_FFN1, TAG_FFN2};
     // decode stream + events (greedy != 0): chunk c's frames are decodable once its layer-11 stage, after_norm and
     // joint.enc_ffn projection are done; the greedy steps run on ctx->dec_stream concurrently with later stages.
-    hipStream_t s2 = s;
+    hipStream_t s2 = s, caller = nullptr;
     if (greedy) {
         if (!ctx->dec_stream) {   // decode = the latency-critical dependent chain: highest stream priority
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             const char* pe = getenv("RNNT_DEC_PRIO");
             const int prio = (pe && pe[0] == '0') ? lo : hi;
-            const char* me = getenv("RNNT_DEC_CUS");   // experiment: reserve the first n CUs of every XCD-interleaved mask for decode
+            const char* me = getenv("RNNT_DEC_CUS");   // experiment: n CUs (every 256/n-th) reserved for decode, the rest for the encoder
             const int ncu = me ? atoi(me) : 0;
             if (ncu > 0) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0; i < ncu && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inv[8];
+                const int step = 256 / ncu;
+                for (int i = 0; i < 256; i += step) mask[i >> 5] |= 1u << (i & 31);
+                for (int i = 0; i < 8; ++i) inv[i] = ~mask[i];
                 HIPCHK(hipExtStreamCreateWithCUMask(&ctx->dec_stream, 8, mask));
+                HIPCHK(hipExtStreamCreateWithCUMask(&ctx->enc_stream, 8, inv));
             } else {
                 HIPCHK(hipStreamCreateWithPriority(&ctx->dec_stream, hipStreamNonBlocking, prio));
             }
@@ -1028,8 +1064,14 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         ctx->pinned[8] = 0;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s));          // everything enqueued before this call (reset, earlier decode)
         HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[C], 0));
+        if (ctx->enc_stream) {                              // experiment: move the wavefront to the masked encoder stream
+            HIPCHK(hipStreamWaitEvent(ctx->enc_stream, ctx->wf_ev[C], 0));
+            caller = s;
+            s = ctx->enc_stream;
+        }
     }
     int dec_steps = 0;
+    std::vector<int> extra_hist(C, 0);
     const int fb0 = ctx->frames_buffered;
     size_t qi = 0;
     static const bool timing = getenv("RNNT_TIMING") != nullptr;
@@ -1074,17 +1116,25 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         if (greedy) {
             HIPCHK(hipEventRecord(ctx->wf_ev[c], s));
             HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c], 0));
-            // Step budget of this chunk: its frames + a little slack + whatever backlog the slowest stream has built up
-            // ("runaway" streams emit up to n_steps symbols per frame).  The backlog is read from pinned memory that
-            // greedy_decide updates every step; to keep it only a few chunks stale the host stays <= LAG chunks ahead.
+            // Step budget of this chunk: its frames + a little slack + the backlog the slowest stream has built up
+            // ("runaway" streams emit up to n_steps symbols per frame).  The backlog (frames behind, written to pinned
+            // memory by greedy_decide) is read LAG chunks late, so the extra steps already enqueued inside that window
+            // are subtracted (delay-compensated feedback; without it the stale backlog is re-added every chunk).
             static const int slack = getenv("RNNT_DEC_SLACK") ? atoi(getenv("RNNT_DEC_SLACK")) : 8;
-            static const int lag = getenv("RNNT_DEC_LAG") ? atoi(getenv("RNNT_DEC_LAG")) : 0;   // 0 = static budgets (feedback overshoots: stale backlog)
-            int backlog = 0;
+            static const int lag = getenv("RNNT_DEC_LAG") ? atoi(getenv("RNNT_DEC_LAG")) : 0;
+            static const int kper = getenv("RNNT_DEC_K") ? atoi(getenv("RNNT_DEC_K")) : 4;
+            int extra = 0;
             if (lag > 0 && c >= lag) {
                 HIPCHK(hipEventSynchronize(ctx->wf_evd[c - lag]));
-                backlog = *(volatile int*)(ctx->pinned + 8);
+                const int backlog = *(volatile int*)(ctx->pinned + 8);
+                int pending = 0;
+                for (int j = c - lag + 1; j < c; ++j) pending += extra_hist[j];
+                extra = backlog * kper - pending;
+                if (extra < 0) extra = 0;
+                if (extra > 48) extra = 48;
             }
-            int budget = ci[c].tq + slack + (backlog > 0 ? (backlog * 6 < 64 ? backlog * 6 : 64) : 0);
+            extra_hist[c] = extra;
+            int budget = ci[c].tq + slack + extra;
             budget = (budget + 3) / 4 * 4;   // few distinct graph sizes
             if ((rc = greedy_steps(ctx, s2, budget, ci[c].fpos + ci[c].tq))) return rc;
             HIPCHK(hipEventRecord(ctx->wf_evd[c], s2));
@@ -1099,7 +1149,7 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         if ((rc = greedy_drain(ctx, s2, fb, dec_steps))) return rc;   // synchronises the decode stream (=> encoder done too)
         ctx->frames_decoded = fb;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));                    // later work on the caller's stream sees the decode
-        HIPCHK(hipStreamWaitEvent(s, ctx->wf_ev[C], 0));
+        HIPCHK(hipStreamWaitEvent(caller ? caller : s, ctx->wf_ev[C], 0));
     }
     return RNNT_OK;
 }

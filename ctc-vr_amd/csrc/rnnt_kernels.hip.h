@@ -85,6 +85,7 @@ struct GemmP {
     const int* nframes;          // EPI_ARGMAX: rows with I[m] >= *nframes are idle (no key written)
     int dbg;       // microbenchmark ablation bits (0 in production): 1 skip global loads, 2 skip MFMAs, 4 skip epilogue
     unsigned a_n1_magic, a_n2_magic, a_seg_magic, c_n_magic, x_n_magic;
+    int a_n1_shift, a_n2_shift, a_seg_shift, c_n_shift, x_n_shift;   // q = umulhi(n, magic) >> shift, exact for n < 2^31
 };
 
 struct GemmBatch {
@@ -113,8 +114,8 @@ __device__ __forceinline__ void stg1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #endif
 
-__device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {   // exact for n*d < 2^32
-    return d == 1 ? n : (int)__umulhi((unsigned)n, magic);
+__device__ __forceinline__ int fastdiv(int n, int d, unsigned magic, int shift) {   // exact for 0 <= n < 2^31
+    return d == 1 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -319,20 +320,20 @@ typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ long long a_row_off(const GemmP& p, int m) {
     if (p.a_plain) return (long long)m * p.a_s2;
-    const int q1 = fastdiv(m, p.a_n1, p.a_n1_magic);
+    const int q1 = fastdiv(m, p.a_n1, p.a_n1_magic, p.a_n1_shift);
     const int r1 = m - q1 * p.a_n1;
-    const int q2 = fastdiv(r1, p.a_n2, p.a_n2_magic);
-    const int r2 = m - fastdiv(m, p.a_n2, p.a_n2_magic) * p.a_n2;
+    const int q2 = fastdiv(r1, p.a_n2, p.a_n2_magic, p.a_n2_shift);
+    const int r2 = m - fastdiv(m, p.a_n2, p.a_n2_magic, p.a_n2_shift) * p.a_n2;
     return (long long)q1 * p.a_s0 + (long long)q2 * p.a_s1 + (long long)r2 * p.a_s2;
 }
 __device__ __forceinline__ long long a_k_off(const GemmP& p, int kk) {
     if (p.a_plain) return kk;
-    const int q = fastdiv(kk, p.a_seg, p.a_seg_magic);
+    const int q = fastdiv(kk, p.a_seg, p.a_seg_magic, p.a_seg_shift);
     return (long long)q * p.a_seg_stride + (kk - q * p.a_seg);
 }
 __device__ __forceinline__ long long c_row_off(const GemmP& p, int m) {
     if (p.c_plain) return (long long)m * p.c_s1;
-    const int q = fastdiv(m, p.c_n, p.c_n_magic);
+    const int q = fastdiv(m, p.c_n, p.c_n_magic, p.c_n_shift);
     int r = m - q * p.c_n + p.c_r0;
     if (r >= p.c_mod) r -= p.c_mod;
     return (long long)q * p.c_s0 + (long long)r * p.c_s1;
@@ -590,7 +591,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
         else if (epi == EPI_SCALE) v = v * p.alpha;
         else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
         else if (epi == EPI_TANH_ADD) {
-            const int bi = fastdiv(m, p.x_n, p.x_n_magic);
+            const int bi = fastdiv(m, p.x_n, p.x_n_magic, p.x_n_shift);
             const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
             v = tanhf(v + ldg1(p.X + (long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n));
         }
@@ -780,7 +781,7 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
                 else if (epi == EPI_SCALE) v = v * p.alpha;
                 else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
                 else if (epi == EPI_TANH_ADD) {
-                    const int bi = fastdiv(m, p.x_n, p.x_n_magic);
+                    const int bi = fastdiv(m, p.x_n, p.x_n_magic, p.x_n_shift);
                     const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
                     v = tanhf(v + ldg1(p.X + (long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n));
                 }
@@ -788,6 +789,12 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
             }
         }
     }
+}
+
+// single-descriptor launch of the LDS-tiled GEMM (conv2 implicit GEMM at M ~ 36 k rows): 2-D grid, descriptor in kernarg
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb) {
+    gemm_ns_body<MT, NT>(gb.g[blockIdx.z], blockIdx.x, blockIdx.y);
 }
 
 // XCD-aware work mapping (guide T1): workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a

@@ -73,7 +73,7 @@ int main() {
     std::vector<Case> cases = {
         {"empty<<<1,64>>>", [&](hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s); }},
         {"empty<<<256,256>>>", [&](hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s); }},
-        {"layer_norm M=192", [&](hipStream_t s) { hipLaunchKernelGGL(layer_norm, dim3(48), dim3(256), 0, s, x, g, bt, y, M, INT_MAX, 0LL, 0, 256LL); }},
+        {"layer_norm M=192", [&](hipStream_t s) { hipLaunchKernelGGL(layer_norm, dim3(48), dim3(256), 0, s, LnP{x, g, bt, y, M, INT_MAX, 0, 0LL, 256LL}); }},
         {"gemm32<8> ffn1 192x1024x256", [&](hipStream_t s) { launch<8>(s, ffn1); }},
         {"gemm32<8> ffn1+LN", [&](hipStream_t s) { launch<8>(s, ffn1ln); }},
         {"gemm32<16> ffn2 192x256x1024", [&](hipStream_t s) { launch<16>(s, ffn2); }},
