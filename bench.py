@@ -96,6 +96,40 @@ def side_workload(args, sd_np, dev, world, rank):
                           "best_tokens_stream0": len(max(beams[0], key=lambda h: h.log_prob).tokens)}}
         print(json.dumps(out))
         return
+    if args.workload == "joint_lattice":
+        # SURVEY.md §8d bench shape of the T x U joint: B=64, T=249 (10 s full-context frames), U=28; output-dominated
+        B, Tn, U, V = 64, 249, 28, T.VOCAB
+        eng = RnntEngine(max_streams=B, max_chunk_frames=16, max_cache_frames=8, max_enc_frames=Tn + 64, vocab_size=V, blank_id=T.BLANK, device=0)
+        eng.load_state_dict(sd_np)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        enc = torch.randn(B, Tn, 256, generator=g).to(dev)
+        prd = (torch.randn(B, U, 256, generator=g) * 0.5).to(dev)
+        out_t = torch.empty(B, Tn, U, V, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        res = {}
+        for mode in (0, 1):
+            for _ in range(args.warmup):
+                eng.joint(enc.data_ptr(), prd.data_ptr(), B, Tn, U, mode, out_t.data_ptr(), s)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.joint(enc.data_ptr(), prd.data_ptr(), B, Tn, U, mode, out_t.data_ptr(), s)
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / args.steps
+        cells = B * Tn * U
+        byts = 4.0 * (B * Tn * 256 + B * U * 256) + 4.0 * (2 * 256 * 256 + 256 * V + 2 * 256 + V) + 4.0 * cells * V
+        fl = 2.0 * cells * 256 * V
+        out = {"metric": "joint lattice cells/sec (add+tanh+projection, logits)", "value": round(cells / res[0], 1), "unit": "lattice-cells/s",
+               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res[0] * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"joint lattice B={B} T={Tn} U={U} V={V} (SURVEY.md §8d), fused tanh-add A-prologue + f32 MFMA projection",
+                          "log_softmax_ms": round(res[1] * 1e3, 3)},
+               "roofline": {"bound": "hbm", "kernel": "rnnt_joint (3 launches)", "achieved": round(byts / res[0] / 1e9, 1), "peak": PEAK_HBM_GBS,
+                            "unit": "GB/s", "frac": round(byts / res[0] / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                            "mfma_tflops": round(fl / res[0] / 1e12, 1), "mfma_frac": round(fl / res[0] / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                            "note": "exact-f32 MFMA makes this shape compute-bound (128 FLOP per output byte vs 19.7 at the f32 peak)"}}
+        print(json.dumps(out))
+        return
     # full context: B x 30 s, decoding_chunk_size = -1
     B, Tn = 32, 3000
     eng = RnntEngine(max_streams=B, max_chunk_frames=Tn, max_cache_frames=760, max_enc_frames=8, vocab_size=T.VOCAB, blank_id=T.BLANK, device=0)
@@ -140,7 +174,7 @@ def main():
                                                                 "B=1 ops are tiny, more threads are slower)")
     ap.add_argument("--also-per-chunk", type=int, default=1, help="also time the per-chunk API mode (reported as extra fields)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "full_context"],
+    ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "full_context", "joint_lattice"],
                     help="greedy = BASELINE configs[1] (default); beam = configs[2] (beam 4, per-chunk); full_context = configs[4]")
     args = ap.parse_args()
 
@@ -178,6 +212,10 @@ def main():
     def step():
         return sb.decode_script(x, args.chunk, per_chunk_decode=per_chunk, pipelined=args.mode == "pipelined")
 
+    side = torch.cuda.Stream(device=dev) if os.environ.get("BENCH_SIDE_STREAM", "1") == "1" else None
+    if side is not None:   # never launch the path on the legacy null stream (implicit cross-stream synchronisation)
+        side.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(side)
     toks = None
     for _ in range(args.warmup):
         toks = step()

@@ -447,13 +447,16 @@ int greedy_steps_raw(rnnt_ctx* ctx, hipStream_t s, int n) {
         GemmP g1 = plain_gemm(ctx->h, D, ctx->whh_il, D, nullptr, ctx->h, D, B, 4 * D, D, EPI_LSTM);
         g1.X = ctx->egate; g1.I = ctx->tok; g1.X2 = ctx->c; g1.Y2 = ctx->c;
         g1.Asel = ctx->sel; g1.asel_stride = bs; g1.asel_invert = 0;
+        g1.act_idx = ctx->fidx; g1.act_lim = ctx->n_active + 2;
         if ((rc = launch_gemm(ctx, s, 0, &g1, 1, TAG_LSTM))) return rc;
         GemmP g3 = plain_gemm(ctx->h, D, ctx->wjc, D, ctx->bjc, ctx->z, D, B, D, D, EPI_TANH_ADD);
         g3.Asel = ctx->sel; g3.asel_stride = bs; g3.asel_invert = 1;   // candidate h' lives in the other buffer
         g3.X = ctx->encp; g3.I = ctx->fidx; g3.x_n = 1; g3.x_s0 = (long long)ctx->fstride * D; g3.x_s1 = D;
+        g3.act_idx = ctx->fidx; g3.act_lim = ctx->n_active + 2;
         if ((rc = launch_gemm(ctx, s, 0, &g3, 1, TAG_JOINT_TANH))) return rc;
         GemmP g4 = plain_gemm(ctx->z, D, ctx->wout, D, ctx->bout, ctx->logits, ctx->vpad, B, V, D, EPI_ARGMAX);
         g4.key = ctx->key; g4.I = ctx->fidx; g4.nframes = ctx->n_active + 2;
+        g4.act_idx = ctx->fidx; g4.act_lim = ctx->n_active + 2;
         if ((rc = launch_gemm(ctx, s, 0, &g4, 1, TAG_JOINT_OUT))) return rc;
     }
     return RNNT_OK;
@@ -1299,21 +1302,30 @@ int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32
     if (!ctx->finalized) return fail(ctx, RNNT_ERR_STATE, "weights not finalized");
     hipStream_t s = (hipStream_t)stream;
     const int V = ctx->cfg.vocab_size;
-    const size_t needf = (size_t)B * T * D + (size_t)B * U * D + (size_t)B * T * U * D;
+    const size_t needf = (size_t)B * T * D + (size_t)B * U * D;
     if (needf > ctx->scratch_floats) return fail(ctx, RNNT_ERR_SHAPE, "joint lattice B=%d T=%d U=%d exceeds the context scratch", B, T, U);
     float* e = ctx->scratch;
-    float* p = e + (size_t)B * T * D;
-    float* zz = p + (size_t)B * U * D;
+    float* pp = e + (size_t)B * T * D;
     int rc;
     GemmP ge = plain_gemm(enc_dev, D, ctx->wenc, D, ctx->benc, e, D, B * T, D, D);
     if ((rc = launch_gemm(ctx, s, 0, &ge, 1))) return rc;
-    // z[b,t,u,:] = tanh(e[b,t,:] + pred_ffn(pred[b,u,:])): rows m = (b,t,u); A row = pred[b,u]; X row = e[b,t]
-    GemmP gz = plain_gemm(pred_dev, D, ctx->wpf, D, ctx->bpf, zz, D, B * T * U, D, D, EPI_TANH_ADD);
-    gz.a_n1 = T * U; gz.a_n2 = U; gz.a_s0 = (long long)U * D; gz.a_s1 = 0; gz.a_s2 = D;
-    gz.X = e; gz.I = nullptr; gz.x_n = U; gz.x_s0 = D; gz.x_s1 = 0;   // row(m) = (m / U) * D
-    if ((rc = launch_gemm(ctx, s, 0, &gz, 1))) return rc;
-    GemmP go = plain_gemm(zz, D, ctx->wout, D, ctx->bout, logits_dev, V, B * T * U, V, D);
-    if ((rc = launch_gemm(ctx, s, 0, &go, 1))) return rc;
+    GemmP gp = plain_gemm(pred_dev, D, ctx->wpf, D, ctx->bpf, pp, D, B * U, D, D);
+    if ((rc = launch_gemm(ctx, s, 0, &gp, 1))) return rc;
+    // logits[b,t,u,:] = tanh(e[b,t,:] + pp[b,u,:]) * W_out^T + b_out in ONE kernel: rows m = (b,t,u); the tanh of the
+    // broadcast sum is formed while the A tile is staged into LDS (no [B,T,U,256] intermediate in HBM).
+    {
+        ProfScope prof(ctx, s, TAG_JOINT_OUT);
+        GemmBatch gb;
+        memset(&gb, 0, sizeof(gb));
+        GemmP& g = gb.g[0];
+        g = plain_gemm(pp, D, ctx->wout, D, ctx->bout, logits_dev, V, B * T * U, V, D);
+        g.a_n1 = T * U; g.a_n2 = U; g.a_s0 = (long long)U * D; g.a_s1 = 0; g.a_s2 = D;   // A row = pp[b, u]
+        g.a_tanh = 1; g.X = e; g.x_n = U; g.x_s0 = D;                                    // X row = e[(b,t)] = e[m / U]
+        if ((rc = prepare_gemm(ctx, g))) return rc;
+        dim3 grid((V + 63) / 64, (g.M + 63) / 64, 1);
+        hipLaunchKernelGGL((gemm_ns<2, 2>), grid, dim3(256), 0, s, gb);
+        LAUNCHCHK("gemm_ns(joint lattice)");
+    }
     if (mode == 1) {
         const long long rows = (long long)B * T * U;
         hipLaunchKernelGGL(log_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits_dev, rows, V);

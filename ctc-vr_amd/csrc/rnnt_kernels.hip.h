@@ -83,6 +83,9 @@ struct GemmP {
     int asel_invert;
     unsigned long long* key;     // EPI_ARGMAX: per-row packed (ordered value, ~index) maximum, atomicMax
     const int* nframes;          // EPI_ARGMAX: rows with I[m] >= *nframes are idle (no key written)
+    int a_tanh;                  // gemm_ns A prologue: a = tanh(A[row(m)][k] + X[(m / x_n) * x_s0 + k]) (joint lattice, joint.py:60-66)
+    const int* act_idx;          // greedy decode: row m is active iff act_idx[m] < *act_lim; a workgroup whose rows are
+    const int* act_lim;          //   all idle exits at once (idle budgeted steps must cost nothing); null = always active
     int dbg;       // microbenchmark ablation bits (0 in production): 1 skip global loads, 2 skip MFMAs, 4 skip epilogue
     unsigned a_n1_magic, a_n2_magic, a_seg_magic, c_n_magic, x_n_magic;
     int a_n1_shift, a_n2_shift, a_seg_shift, c_n_shift, x_n_shift;   // q = umulhi(n, magic) >> shift, exact for n < 2^31
@@ -349,6 +352,16 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
     const int m0 = blockIdx.y * (16 * MT), n0 = blockIdx.x * (16 * NT);
     if (m0 >= p.M || n0 >= p.N) return;
     const int i = lane & 15, kq = lane >> 4;
+    if (p.act_idx) {   // uniform per workgroup: every wave evaluates the same 16*MT rows
+        const int lim = ldgi(p.act_lim);
+        bool any = false;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + 16 * mt + i;
+            any = any || (m < p.M && ldgi(p.act_idx + m) < lim);
+        }
+        if (!__any(any)) return;
+    }
 
     const float* arow[MT];
 #pragma unroll
@@ -666,12 +679,15 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     const int c4 = (tid & 7) * 4;
     const int srow = tid >> 3;
     const float* ag[MT];
+    const float* xg[MT];
     const float* wg[NT];
     float amean[MT], arstd[MT];
+    const bool atanh_ = p.a_tanh != 0;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int am = min(bm0 + srow + 32 * j, p.M - 1);
         ag[j] = p.A + a_row_off(p, am);
+        xg[j] = atanh_ ? p.X + (long long)fastdiv(am, p.x_n, p.x_n_magic, p.x_n_shift) * p.x_s0 : p.A;
         if (p.Asel) ag[j] += (long long)(ldgi(p.Asel + am) ^ p.asel_invert) * p.asel_stride;
         amean[j] = ln ? st[(srow + 32 * j) * 2] : 0.f;
         arstd[j] = ln ? st[(srow + 32 * j) * 2 + 1] : 1.f;
@@ -688,13 +704,16 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     const int wm = (wave >> 1) * (16 * MT), wn = (wave & 1) * (16 * NT);   // this wave's sub-tile inside the workgroup tile
     const int nb = p.K / NS_BK;
     const bool aplain = p.a_plain != 0;
-    float4 ra[MT], rw[NT], rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[MT], rx[MT], rw[NT], rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #define NS_GLOAD(blk_)                                                                                         \
     {                                                                                                          \
         const int kk_ = (blk_) * NS_BK + c4;                                                                   \
         const long long ko_ = aplain ? (long long)kk_ : a_k_off(p, kk_);                                       \
         _Pragma("unroll") for (int j = 0; j < MT; ++j) ra[j] = ldg4(ag[j] + ko_);                              \
+        if (atanh_) { _Pragma("unroll") for (int j = 0; j < MT; ++j) rx[j] = ldg4(xg[j] + kk_); }              \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) rw[j] = ldg4(wg[j] + kk_);                              \
         if (ln) {                                                                                              \
             rg = ldg4(p.ln_g + kk_);                                                                           \
@@ -705,6 +724,12 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     {                                                                                                          \
         _Pragma("unroll") for (int j = 0; j < MT; ++j) {                                                       \
             float4 v_ = ra[j];                                                                                 \
+            if (atanh_) {                                                                                      \
+                v_.x = tanhf(v_.x + rx[j].x);                                                                  \
+                v_.y = tanhf(v_.y + rx[j].y);                                                                  \
+                v_.z = tanhf(v_.z + rx[j].z);                                                                  \
+                v_.w = tanhf(v_.w + rx[j].w);                                                                  \
+            }                                                                                                  \
             if (ln) {                                                                                          \
                 v_.x = (v_.x - amean[j]) * arstd[j] * rg.x + rb.x;                                             \
                 v_.y = (v_.y - amean[j]) * arstd[j] * rg.y + rb.y;                                             \
