@@ -62,7 +62,10 @@ struct rnnt_ctx {
     float *h = nullptr, *c = nullptr, *pred = nullptr, *z = nullptr, *logits = nullptr;
     int *tok = nullptr, *fidx = nullptr, *nsym = nullptr, *count = nullptr, *tokens = nullptr, *n_active = nullptr, *klen = nullptr, *sel = nullptr;
     unsigned long long* key = nullptr;
+    int* dec_ctrl = nullptr;   // persistent decoder control block: [0] frames_ready, [1] error, [2] evaluations
+    int use_persistent = 1;
     const float *wjc = nullptr, *bjc = nullptr;   // folded joint.pred_ffn o predictor.projection
+    const float *wctc = nullptr, *bctc = nullptr; // ctc_head.ctc_lo (optional)
     // beam search: state pools [rows][n_steps+1][512] (ping-pong), per-row buffers
     int max_rows = 0;
     float *pool[2] = {nullptr, nullptr}, *bpred = nullptr, *bz = nullptr, *blogits = nullptr, *b_blank = nullptr, *b_toplp = nullptr;
@@ -402,13 +405,17 @@ int launch_gemm_tab(rnnt_ctx* ctx, hipStream_t s, const GemmP* tab_dev, int n, i
     ProfScope prof(ctx, s, tag);
     static const int ns_mode = getenv("RNNT_GEMM_NS") ? atoi(getenv("RNNT_GEMM_NS")) : 1;
     if (ns_mode && n >= 6 && K % 32 == 0) {   // enough groups: no split-K, epilogue from registers
-        const int ntn = (N + 63) / 64;
-        if (K >= 1024 || N <= 256) {          // 32x64 workgroup tiles (more workgroups for the narrow / deep shapes)
-            const int ntm = (maxM + 31) / 32;
-            hipLaunchKernelGGL((gemm_ns_tab<1, 2>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
-        } else {                              // 64x64 workgroup tiles
-            const int ntm = (maxM + 63) / 64;
-            hipLaunchKernelGGL((gemm_ns_tab<2, 2>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+        // tile choice from tools/microbench2.hip (12 groups x 192 rows): the kernel is occupancy/latency-bound, so the
+        // narrow shapes want many small workgroups; only K = 1024 profits from 64-deep K blocks (half the barriers)
+        if (N >= 512) {                       // ffn1 / pointwise_conv1: 32x64 tiles
+            const int ntn = (N + 63) / 64, ntm = (maxM + 31) / 32;
+            hipLaunchKernelGGL((gemm_ns_tab<1, 2, 32>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+        } else if (K >= 1024) {               // ffn2: 32x32 tiles, BK = 64
+            const int ntn = (N + 31) / 32, ntm = (maxM + 31) / 32;
+            hipLaunchKernelGGL((gemm_ns_tab<1, 1, 64>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+        } else {                              // q/k/v, linear_out, pointwise_conv2: 32x32 tiles
+            const int ntn = (N + 31) / 32, ntm = (maxM + 31) / 32;
+            hipLaunchKernelGGL((gemm_ns_tab<1, 1, 32>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
         }
         LAUNCHCHK("gemm_ns_tab");
         return RNNT_OK;
@@ -519,6 +526,52 @@ int greedy_drain(rnnt_ctx* ctx, hipStream_t s, int n_frames, int done_steps) {
     return RNNT_OK;
 }
 
+// Persistent greedy decoder: one resident workgroup per 2 streams decodes every frame up to n_total, waiting on
+// dec_ctrl[0] (frames_ready).  The control block must have been initialised on a stream this one is ordered after.
+int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total) {
+    DecP d;
+    memset(&d, 0, sizeof(d));
+    d.whh = ctx->whh_il; d.egate = ctx->egate; d.wjc = ctx->wjc; d.bjc = ctx->bjc; d.wout = ctx->wout; d.bout = ctx->bout;
+    d.encp = ctx->encp; d.h = ctx->h; d.c = ctx->c; d.sel = ctx->sel; d.tok = ctx->tok; d.fidx = ctx->fidx; d.nsym = ctx->nsym;
+    d.count = ctx->count; d.tokens = ctx->tokens; d.ctrl = ctx->dec_ctrl;
+    d.fstride_f = (long long)ctx->fstride * D; d.bstride = (long long)ctx->cfg.max_streams * D;
+    d.B = ctx->n_streams; d.vocab = ctx->cfg.vocab_size; d.blank = ctx->cfg.blank_id; d.n_steps = ctx->cfg.n_steps;
+    d.max_tokens = ctx->cfg.max_tokens; d.n_total = n_total;
+    d.timeout_ticks = 500000000ll;   // 5 s of the 100 MHz real-time counter: every wait in the kernel is bounded
+    static const int dth = getenv("RNNT_DEC_THREADS") ? atoi(getenv("RNNT_DEC_THREADS")) : 512;   // 1 stream / 512 threads: no spills,
+    static const int spw = getenv("RNNT_DEC_SPW") ? atoi(getenv("RNNT_DEC_SPW")) : 1;             // best of the measured variants
+    const int B = ctx->n_streams;
+    if (spw == 1) {
+        if (dth == 512) hipLaunchKernelGGL((greedy_persistent<1, 512>), dim3(B), dim3(512), 0, s, d);
+        else hipLaunchKernelGGL((greedy_persistent<1, 1024>), dim3(B), dim3(1024), 0, s, d);
+    } else if (spw == 4) {
+        hipLaunchKernelGGL((greedy_persistent<4, 1024>), dim3((B + 3) / 4), dim3(1024), 0, s, d);
+    } else {
+        if (dth == 256) hipLaunchKernelGGL((greedy_persistent<2, 256>), dim3((B + 1) / 2), dim3(256), 0, s, d);
+        else if (dth == 512) hipLaunchKernelGGL((greedy_persistent<2, 512>), dim3((B + 1) / 2), dim3(512), 0, s, d);
+        else hipLaunchKernelGGL((greedy_persistent<2, 1024>), dim3((B + 1) / 2), dim3(1024), 0, s, d);
+    }
+    LAUNCHCHK("greedy_persistent");
+    return RNNT_OK;
+}
+
+int init_decoder_ctrl(rnnt_ctx* ctx, hipStream_t s, int frames_ready) {
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->dec_ctrl, 0, 8LL);
+    LAUNCHCHK("fill_i32");
+    hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, frames_ready);
+    LAUNCHCHK("publish_frames");
+    return RNNT_OK;
+}
+
+// wait for the decoder and check its error word; updates the evaluation counter
+int finish_persistent_decoder(rnnt_ctx* ctx, hipStream_t s) {
+    HIPCHK(hipMemcpyAsync(ctx->pinned + 12, ctx->dec_ctrl, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->greedy_steps += ctx->pinned[14];
+    if (ctx->pinned[13] != 0) return fail(ctx, RNNT_ERR_STATE, "persistent decoder timed out waiting for encoder frames");
+    return RNNT_OK;
+}
+
 template <typename T>
 int grow(rnnt_ctx* ctx, T** p, size_t* cap, size_t need) {
     if (need <= *cap) return RNNT_OK;
@@ -549,6 +602,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
         return fail(ctx, RNNT_ERR_ARG, "rnnt_create: bad config");
     HIPCHK(hipSetDevice(cfg->device));
     if (const char* ng = getenv("RNNT_NO_GRAPH")) ctx->use_graphs = (ng[0] == '1') ? 0 : 1;
+    if (const char* pe = getenv("RNNT_PERSISTENT")) ctx->use_persistent = (pe[0] == '0') ? 0 : 1;
     const int B = cfg->max_streams;
     ctx->tmax = sub_len(cfg->max_chunk_frames);
     ctx->t1max = sub1_len(cfg->max_chunk_frames);
@@ -576,7 +630,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     ALLOC(h, (size_t)2 * B * D); ALLOC(c, (size_t)2 * B * D); ALLOC(sel, B); ALLOC(key, B);
     ALLOC(pred, (size_t)B * D); ALLOC(z, (size_t)B * D); ALLOC(logits, (size_t)B * ctx->vpad);
     ALLOC(tok, B); ALLOC(fidx, B); ALLOC(nsym, B); ALLOC(count, B); ALLOC(tokens, (size_t)B * cfg->max_tokens);
-    ALLOC(n_active, 4); ALLOC(klen, B);
+    ALLOC(n_active, 4); ALLOC(klen, B); ALLOC(dec_ctrl, 8);
     if (cfg->max_beam > 0) {
         ctx->max_rows = B * cfg->max_beam;
         const size_t R = ctx->max_rows, NS = cfg->n_steps, KB = cfg->max_beam;
@@ -598,7 +652,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
 void rnnt_destroy(rnnt_ctx* ctx) {
     if (!ctx) return;
     void* ptrs[] = {ctx->blob, ctx->egate, ctx->y1, ctx->y2, ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf, ctx->kcache, ctx->vcache,
-                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->pred, ctx->z, ctx->logits,
+                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->dec_ctrl, ctx->pred, ctx->z, ctx->logits,
                     ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch,
                     ctx->pool[0], ctx->pool[1], ctx->bpred, ctx->bz, ctx->blogits, ctx->b_blank, ctx->b_toplp, ctx->b_toptok,
                     ctx->b_tok, ctx->b_frame, ctx->b_active, ctx->b_steps, ctx->b_srcrow, ctx->b_srcstep};
@@ -806,6 +860,13 @@ int rnnt_finalize_weights(rnnt_ctx* ctx, int32_t numerics_mode, void* stream) {
         }
         putv(&ctx->wjc, wc);
         putv(&ctx->bjc, bc);
+        const HostTensor* cw = find(ctx, "ctc_head.ctc_lo.weight");
+        const HostTensor* cb = find(ctx, "ctc_head.ctc_lo.bias");
+        ctx->wctc = ctx->bctc = nullptr;
+        if (cw && cb && cw->dims == std::vector<int64_t>{V, D} && cb->dims == std::vector<int64_t>{V}) {
+            put(&ctx->wctc, cw->data.data(), cw->data.size());
+            put(&ctx->bctc, cb->data.data(), V);
+        }
     }
 #undef NEED
     // upload
@@ -1065,8 +1126,10 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             ctx->wf_evd.push_back(e);
         }
         ctx->pinned[8] = 0;
+        if (ctx->use_persistent && (rc = init_decoder_ctrl(ctx, s, ctx->frames_buffered))) return rc;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s));          // everything enqueued before this call (reset, earlier decode)
         HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[C], 0));
+        if (ctx->use_persistent && (rc = launch_persistent_decoder(ctx, s2, fb))) return rc;
         if (ctx->enc_stream) {                              // experiment: move the wavefront to the masked encoder stream
             HIPCHK(hipStreamWaitEvent(ctx->enc_stream, ctx->wf_ev[C], 0));
             caller = s;
@@ -1116,7 +1179,10 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
         }
         if (timing) { double t = now(); t_enc += t - tl; tl = t; }
-        if (greedy) {
+        if (greedy && ctx->use_persistent) {   // the resident decoder sees the chunk's frames as soon as this lands
+            hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, ci[c].fpos + ci[c].tq);
+            LAUNCHCHK("publish_frames");
+        } else if (greedy) {
             HIPCHK(hipEventRecord(ctx->wf_ev[c], s));
             HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c], 0));
             // Step budget of this chunk: its frames + a little slack + the backlog the slowest stream has built up
@@ -1148,7 +1214,12 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     if (timing) fprintf(stderr, "[rnnt timing] host enqueue: encoder stages %.2f ms, decode batches %.2f ms\n", t_enc, t_dec);
     if (frames_out) *frames_out = fb - fb0;
     ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
-    if (greedy) {
+    if (greedy && ctx->use_persistent) {
+        if ((rc = finish_persistent_decoder(ctx, s2))) return rc;      // synchronises the decode stream (=> encoder done too)
+        ctx->frames_decoded = fb;
+        HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));
+        HIPCHK(hipStreamWaitEvent(caller ? caller : s, ctx->wf_ev[C], 0));
+    } else if (greedy) {
         if ((rc = greedy_drain(ctx, s2, fb, dec_steps))) return rc;   // synchronises the decode stream (=> encoder done too)
         ctx->frames_decoded = fb;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));                    // later work on the caller's stream sees the decode
@@ -1164,6 +1235,13 @@ int rnnt_greedy_decode(rnnt_ctx* ctx, void* stream) {
     const int nf = ctx->frames_buffered;
     if (nf <= ctx->frames_decoded) return RNNT_OK;
     int rc;
+    if (ctx->use_persistent) {
+        if ((rc = init_decoder_ctrl(ctx, s, nf))) return rc;
+        if ((rc = launch_persistent_decoder(ctx, s, nf))) return rc;
+        if ((rc = finish_persistent_decoder(ctx, s))) return rc;
+        ctx->frames_decoded = nf;
+        return RNNT_OK;
+    }
     const int first = nf - ctx->frames_decoded + 2;
     if ((rc = greedy_steps(ctx, s, first, nf))) return rc;
     if ((rc = greedy_drain(ctx, s, nf, first))) return rc;
@@ -1364,6 +1442,34 @@ int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens
     for (int l = 0; l < L; ++l)
         if ((rc = run_layer(ctx, s, l, B, tq, tq, 0, 0, 0, ctx->klen))) return rc;
     if ((rc = launch_ln(ctx, s, LnP{ctx->x, ctx->after_g, ctx->after_b, out_dev, B * tq, BIG, 0, 0LL, (long long)D}))) return rc;
+    if (frames_out) *frames_out = tq;
+    return RNNT_OK;
+}
+
+// OnlineCTC.argmax over the full-context encoder (model/online_rnnt_model.py:37-38,655-658): per-frame argmax of
+// ctc_lo(encoder(x)) for B utterances; ids_host [B, T'] int32.  The collapse rule (:660-671) stays on the host.
+int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T, int32_t* ids_host,
+                    int32_t* frames_out, void* stream) {
+    if (!ctx || !ids_host) return fail(ctx, RNNT_ERR_ARG, "rnnt_ctc_argmax: null argument");
+    if (!ctx->finalized) return fail(ctx, RNNT_ERR_STATE, "weights not finalized");
+    if (!ctx->wctc) return fail(ctx, RNNT_ERR_STATE, "rnnt_ctc_argmax: ctc_head.ctc_lo.* not loaded");
+    hipStream_t s = (hipStream_t)stream;
+    const int tq = sub_len(T);
+    const size_t rows = (size_t)B * tq;
+    if (rows * D + rows * 3 > ctx->scratch_floats) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_ctc_argmax: B=%d T=%d exceeds the context scratch", B, T);
+    float* enc = ctx->scratch;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(ctx->scratch + ((rows * D + 1) / 2) * 2);
+    int* ids = reinterpret_cast<int*>(keys + rows);
+    int rc, fo = 0;
+    if ((rc = rnnt_encoder_full(ctx, fbank_dev, lens_host, B, T, enc, &fo, stream))) return rc;
+    HIPCHK(hipMemsetAsync(keys, 0, rows * sizeof(unsigned long long), s));
+    GemmP g = plain_gemm(enc, D, ctx->wctc, D, ctx->bctc, nullptr, 0, (int)rows, ctx->cfg.vocab_size, D, EPI_ARGMAX);
+    g.key = keys;
+    if ((rc = launch_gemm(ctx, s, 0, &g, 1))) return rc;   // EPI_ARGMAX always takes the gemm16 (split-K) kernel
+    hipLaunchKernelGGL(unpack_keys, dim3(grid_for((long long)rows)), dim3(256), 0, s, keys, ids, (long long)rows);
+    LAUNCHCHK("unpack_keys");
+    HIPCHK(hipMemcpyAsync(ids_host, ids, rows * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     if (frames_out) *frames_out = tq;
     return RNNT_OK;
 }

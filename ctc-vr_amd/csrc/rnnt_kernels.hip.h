@@ -588,7 +588,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
                 const int oi = __shfl_xor(bi, o, 16);
                 if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; }
             }
-            if ((ln_ & 15) == 0 && idx < NEL && m < p.M && bi != 0x7fffffff && ldgi(p.I + m) < ldgi(p.nframes)) {
+            if ((ln_ & 15) == 0 && idx < NEL && m < p.M && bi != 0x7fffffff && (!p.I || ldgi(p.I + m) < ldgi(p.nframes))) {
                 unsigned u = __float_as_uint(v);
                 u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // order-preserving float -> uint
                 const unsigned long long k64 = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi);
@@ -633,11 +633,14 @@ __global__ __launch_bounds__(64 * WK) void gemm16_tab(const GemmP* __restrict__ 
 // LDS rows are padded to 36 floats: the 16 rows of a ds_read_b128 fragment read start on 16 distinct 4-bank groups.
 // The LayerNorm prologue is applied while the A tile is written to LDS.
 // ------------------------------------------------------------------------------------------------
-#define NS_BK 32
-#define NS_LD 36
-template <int MT, int NT>
+template <int MT, int NT, int NS_BK = 32>
 __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int NS_LD = NS_BK + 4;       // row stride in floats: 16 fragment rows start on 16 distinct 4-bank groups
+    constexpr int LPR = NS_BK / 4;         // float4 slots per tile row (8 for BK = 32, 16 for BK = 64)
+    constexpr int RPP = 256 / LPR;         // tile rows staged per pass of the 256 threads
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+    constexpr int AJ = BM / RPP, WJ = BN / RPP;
     __shared__ __attribute__((aligned(16))) float As[2][BM * NS_LD];
     __shared__ __attribute__((aligned(16))) float Ws[2][BN * NS_LD];
     __shared__ float st[2 * BM];
@@ -675,25 +678,25 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
         __syncthreads();
     }
 
-    // staging assignment: float4 slot s = tid + 256*j covers tile row s/8, columns 4*(s%8)..+3
-    const int c4 = (tid & 7) * 4;
-    const int srow = tid >> 3;
-    const float* ag[MT];
-    const float* xg[MT];
-    const float* wg[NT];
-    float amean[MT], arstd[MT];
+    // staging assignment: thread covers tile rows srow + RPP*j, columns c4..c4+3 of the current K block
+    const int c4 = (tid % LPR) * 4;
+    const int srow = tid / LPR;
+    const float* ag[AJ];
+    const float* xg[AJ];
+    const float* wg[WJ];
+    float amean[AJ], arstd[AJ];
     const bool atanh_ = p.a_tanh != 0;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int am = min(bm0 + srow + 32 * j, p.M - 1);
+    for (int j = 0; j < AJ; ++j) {
+        const int am = min(bm0 + srow + RPP * j, p.M - 1);
         ag[j] = p.A + a_row_off(p, am);
         xg[j] = atanh_ ? p.X + (long long)fastdiv(am, p.x_n, p.x_n_magic, p.x_n_shift) * p.x_s0 : p.A;
         if (p.Asel) ag[j] += (long long)(ldgi(p.Asel + am) ^ p.asel_invert) * p.asel_stride;
-        amean[j] = ln ? st[(srow + 32 * j) * 2] : 0.f;
-        arstd[j] = ln ? st[(srow + 32 * j) * 2 + 1] : 1.f;
+        amean[j] = ln ? st[(srow + RPP * j) * 2] : 0.f;
+        arstd[j] = ln ? st[(srow + RPP * j) * 2 + 1] : 1.f;
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wg[j] = p.W + (long long)min(bn0 + srow + 32 * j, p.N - 1) * p.ldw;
+    for (int j = 0; j < WJ; ++j) wg[j] = p.W + (long long)min(bn0 + srow + RPP * j, p.N - 1) * p.ldw;
 
     f32x4_ acc[MT][NT];
 #pragma unroll
@@ -704,17 +707,17 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     const int wm = (wave >> 1) * (16 * MT), wn = (wave & 1) * (16 * NT);   // this wave's sub-tile inside the workgroup tile
     const int nb = p.K / NS_BK;
     const bool aplain = p.a_plain != 0;
-    float4 ra[MT], rx[MT], rw[NT], rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[AJ], rx[AJ], rw[WJ], rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < MT; ++j) rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < AJ; ++j) rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #define NS_GLOAD(blk_)                                                                                         \
     {                                                                                                          \
         const int kk_ = (blk_) * NS_BK + c4;                                                                   \
         const long long ko_ = aplain ? (long long)kk_ : a_k_off(p, kk_);                                       \
-        _Pragma("unroll") for (int j = 0; j < MT; ++j) ra[j] = ldg4(ag[j] + ko_);                              \
-        if (atanh_) { _Pragma("unroll") for (int j = 0; j < MT; ++j) rx[j] = ldg4(xg[j] + kk_); }              \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) rw[j] = ldg4(wg[j] + kk_);                              \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = ldg4(ag[j] + ko_);                              \
+        if (atanh_) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) rx[j] = ldg4(xg[j] + kk_); }              \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j) rw[j] = ldg4(wg[j] + kk_);                              \
         if (ln) {                                                                                              \
             rg = ldg4(p.ln_g + kk_);                                                                           \
             rb = ldg4(p.ln_b + kk_);                                                                           \
@@ -722,7 +725,7 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     }
 #define NS_LSTORE(buf_)                                                                                        \
     {                                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < MT; ++j) {                                                       \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                       \
             float4 v_ = ra[j];                                                                                 \
             if (atanh_) {                                                                                      \
                 v_.x = tanhf(v_.x + rx[j].x);                                                                  \
@@ -736,10 +739,10 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
                 v_.z = (v_.z - amean[j]) * arstd[j] * rg.z + rb.z;                                             \
                 v_.w = (v_.w - amean[j]) * arstd[j] * rg.w + rb.w;                                             \
             }                                                                                                  \
-            *reinterpret_cast<float4*>(&As[buf_][(srow + 32 * j) * NS_LD + c4]) = v_;                          \
+            *reinterpret_cast<float4*>(&As[buf_][(srow + RPP * j) * NS_LD + c4]) = v_;                         \
         }                                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
-            *reinterpret_cast<float4*>(&Ws[buf_][(srow + 32 * j) * NS_LD + c4]) = rw[j];                       \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j)                                                         \
+            *reinterpret_cast<float4*>(&Ws[buf_][(srow + RPP * j) * NS_LD + c4]) = rw[j];                      \
     }
 
     NS_GLOAD(0)
@@ -817,9 +820,9 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
 }
 
 // single-descriptor launch of the LDS-tiled GEMM (conv2 implicit GEMM at M ~ 36 k rows): 2-D grid, descriptor in kernarg
-template <int MT, int NT>
+template <int MT, int NT, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb) {
-    gemm_ns_body<MT, NT>(gb.g[blockIdx.z], blockIdx.x, blockIdx.y);
+    gemm_ns_body<MT, NT, BK>(gb.g[blockIdx.z], blockIdx.x, blockIdx.y);
 }
 
 // XCD-aware work mapping (guide T1): workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb) {
 // every XCD touches all of them and the operands stream from the Infinity Cache.  Here each (descriptor,
 // column-tile) pair -- i.e. one 64-row slice of one weight matrix -- is pinned to ONE XCD and its M-tiles run
 // there back to back, so a slice is fetched once per launch.  Placement is a speed hint only.
-template <int MT, int NT>
+template <int MT, int NT, int BK = 32>
 __global__ __launch_bounds__(256) void gemm_ns_tab(const GemmP* __restrict__ tab, int n_desc, int ntn, int ntm) {
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(256) void gemm_ns_tab(const GemmP* __restrict__ tab
     if (pair >= n_desc * ntn) return;
     const int g = pair / ntn;
     const GemmP p = tab[g];   // by-value copy: the fields live in SGPRs instead of being re-read inside the K loop
-    gemm_ns_body<MT, NT>(p, pair - g * ntn, slot % ntm);
+    gemm_ns_body<MT, NT, BK>(p, pair - g * ntn, slot % ntm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,6 +1188,261 @@ __global__ __launch_bounds__(64) void greedy_decide(int B, int blank, int n_step
         for (int o = 32; o > 0; o >>= 1) act += __shfl_xor(act, o, 64);
         if (threadIdx.x == 0) st.misc[0] = act;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy_persistent<SPW>: the whole greedy decode of an utterance batch as ONE resident kernel.
+// One workgroup owns SPW streams for the whole call and runs their RNN-T greedy state machine
+// (_decode_chunk_streaming_logic, online_rnnt_model.py:193-220) without any exchange with other workgroups:
+//   LSTM cell      gates = E[tok] + W_hh h      (predictor.py:200-204; gate rows interleaved i,f,g,o per unit)
+//   joint          z = tanh(enc_proj[t] + W_c h' + b_c), W_c = W_pf W_pr folded (joint.py:54-66)
+//   vocabulary     logits = W_out z + b_out, argmax (first index on ties, online_rnnt_model.py:212)
+//   decision       blank -> next frame; else emit, commit (h', c'), <= n_steps symbols per frame.
+// Streams are independent, so there is no lock step between workgroups: a "runaway" stream (n_steps symbols on many
+// frames) only delays itself.  The lock-stepped launch-per-evaluation path needed 4 dependent kernels (~21 us, ~30 us
+// when the encoder's grids fill the dispatcher) per evaluation of the SLOWEST stream; here an evaluation is ~1.7 MB of
+// weight rows streamed from L2 by one CU plus ~0.4 MFLOP of VALU dot products.
+// Matrix-vector layout: 16 lanes per weight row (16 x float4 = 256 contiguous bytes per load instruction and row,
+// 4 loads cover K = 256), 16 rows per pass of the 256 threads, partial sums reduced with 4 in-row shuffles.
+// Frames arrive while the kernel runs: the encoder stream publishes `frames_ready` after each chunk's joint.enc_ffn
+// projection (kernel boundary = release); thread 0 polls it with relaxed agent-scope loads and, when it grows, issues
+// ONE agent-scope acquire fence before anyone reads the new enc_proj rows.  Every wait is bounded (wall clock).
+// ------------------------------------------------------------------------------------------------
+struct DecP {
+    const float* whh;     // [1024][256] gate-interleaved
+    const float* egate;   // [vocab][1024] gate-interleaved input table
+    const float* wjc;     // [256][256] folded pred_ffn o projection
+    const float* bjc;     // [256]
+    const float* wout;    // [vocab][256]
+    const float* bout;    // [vocab]
+    const float* encp;    // [B][fstride][256] projected encoder frames
+    float* h;             // [2][bstride] state buffers (committed one selected by sel[b])
+    float* c;
+    int* sel;
+    int* tok;
+    int* fidx;
+    int* nsym;
+    int* count;
+    int* tokens;          // [B][max_tokens]
+    int* ctrl;            // [0] frames_ready (published by the encoder stream), [1] error flag, [2] evaluations (stats)
+    long long fstride_f;  // floats between streams in encp
+    long long bstride;    // floats between the two state buffers
+    int B, vocab, blank, n_steps, max_tokens, n_total;
+    long long timeout_ticks;   // s_memrealtime ticks (100 MHz)
+};
+
+template <int SPW, int NTH, typename Epi>
+__device__ __forceinline__ void dec_matvec(const float* __restrict__ W, int nrows, const float (*x)[RNNT_D], Epi epi) {
+    const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
+    float4 xv[SPW][4];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[s][j] = *reinterpret_cast<const float4*>(&x[s][4 * l + 64 * j]);
+    constexpr int U = 2;            // weight rows in flight per lane group (x NTH/16 groups: 128 KB per CU at 1024 threads)
+    constexpr int RP = NTH / 16;    // rows per pass of the workgroup
+    for (int r0 = 0; r0 < nrows; r0 += RP * U) {
+        float4 w[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = min(r0 + RP * u + g, nrows - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[u][j] = ldg4(W + (long long)n * RNNT_D + 4 * l + 64 * j);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = r0 + RP * u + g;
+            float acc[SPW];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a = fmaf(w[u][j].x, xv[s][j].x, a);
+                    a = fmaf(w[u][j].y, xv[s][j].y, a);
+                    a = fmaf(w[u][j].z, xv[s][j].z, a);
+                    a = fmaf(w[u][j].w, xv[s][j].w, a);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+                acc[s] = a;
+            }
+            if (l == 0 && n < nrows) epi(n, acc);
+        }
+    }
+}
+
+template <int SPW, int NTH>
+__global__ __launch_bounds__(NTH) void greedy_persistent(DecP p) {
+    __shared__ __attribute__((aligned(16))) float hs[SPW][RNNT_D], cs[SPW][RNNT_D], h2[SPW][RNNT_D], c2[SPW][RNNT_D], zs[SPW][RNNT_D];
+    __shared__ __attribute__((aligned(16))) float gates[SPW][4 * RNNT_D];
+    __shared__ float redv[NTH / 16][SPW];
+    __shared__ int redi[NTH / 16][SPW];
+    __shared__ int s_tok[SPW], s_fidx[SPW], s_nsym[SPW], s_count[SPW], s_valid[SPW], s_active[SPW], s_ctl[4];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * SPW;
+    if (b0 >= p.B) return;
+    // ---- load the streams' state (committed LSTM buffer, token, frame cursor) -------------------------------------
+    for (int e = tid; e < SPW * RNNT_D; e += NTH) {
+        const int s = e >> 8, j = e & 255, b = b0 + s;
+        float hv = 0.f, cv = 0.f;
+        if (b < p.B) {
+            const long long off = (long long)(ldgi(p.sel + b) & 1) * p.bstride + (long long)b * RNNT_D + j;
+            hv = ldg1(p.h + off);
+            cv = ldg1(p.c + off);
+        }
+        hs[s][j] = hv;
+        cs[s][j] = cv;
+    }
+    if (tid < SPW) {
+        const int b = b0 + tid;
+        const bool v = b < p.B;
+        s_valid[tid] = v ? 1 : 0;
+        s_tok[tid] = v ? ldgi(p.tok + b) : p.blank;
+        s_fidx[tid] = v ? ldgi(p.fidx + b) : p.n_total;
+        s_nsym[tid] = v ? ldgi(p.nsym + b) : 0;
+        s_count[tid] = v ? ldgi(p.count + b) : 0;
+    }
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; }
+    __syncthreads();
+    int evals = 0;
+    int seen_ready = 0;
+    while (true) {
+        // ---- wait until one of my streams has a frame to decode (or everything is decoded) -----------------------
+        if (tid == 0) {
+            int done = 1, any = 0;
+            int nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+            while (true) {
+                done = 1; any = 0;
+                for (int s = 0; s < SPW; ++s) {
+                    const int f = s_fidx[s];
+                    if (s_valid[s] && f < p.n_total) done = 0;
+                    const int act = (s_valid[s] && f < nf) ? 1 : 0;
+                    s_active[s] = act;
+                    any |= act;
+                }
+                if (done || any) break;
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {   // bounded wait: give up loudly
+                    __hip_atomic_store(p.ctrl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    done = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+                nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (nf > seen_ready) {   // new frames became visible: ONE acquire so that nobody reads stale enc_proj lines
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                seen_ready = nf;
+            }
+            s_ctl[0] = done;
+        }
+        __syncthreads();
+        if (s_ctl[0]) break;
+        // ---- LSTM gates: gates[s][n] = E[tok_s][n] + W_hh[n] . h_s -------------------------------------------------
+        dec_matvec<SPW, NTH>(p.whh, 4 * RNNT_D, hs, [&](int n, const float* acc) {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) gates[s][n] = acc[s] + ldg1(p.egate + (long long)s_tok[s] * (4 * RNNT_D) + n);
+        });
+        __syncthreads();
+        for (int e = tid; e < SPW * RNNT_D; e += NTH) {
+            const int s = e >> 8, j = e & 255;
+            const float4 gt = *reinterpret_cast<const float4*>(&gates[s][4 * j]);
+            const float cc = sigmoidf_(gt.y) * cs[s][j] + sigmoidf_(gt.x) * tanhf(gt.z);
+            c2[s][j] = cc;
+            h2[s][j] = sigmoidf_(gt.w) * tanhf(cc);
+        }
+        __syncthreads();
+        // ---- joint: z = tanh(enc_proj[b][t] + W_c h' + b_c) ---------------------------------------------------------
+        dec_matvec<SPW, NTH>(p.wjc, RNNT_D, h2, [&](int n, const float* acc) {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                float e = 0.f;
+                if (s_active[s]) e = ldg1(p.encp + (long long)(b0 + s) * p.fstride_f + (long long)s_fidx[s] * RNNT_D + n);
+                zs[s][n] = tanhf(acc[s] + ldg1(p.bjc + n) + e);
+            }
+        });
+        __syncthreads();
+        // ---- vocabulary projection + argmax (rows ascend per lane group: strict > keeps the first maximum) -------
+        float bv[SPW];
+        int bi[SPW];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) { bv[s] = -INFINITY; bi[s] = 0x7fffffff; }
+        dec_matvec<SPW, NTH>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
+            const float bo = ldg1(p.bout + n);
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const float v = acc[s] + bo;
+                if (v > bv[s]) { bv[s] = v; bi[s] = n; }
+            }
+        });
+        if ((tid & 15) == 0) {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) { redv[tid >> 4][s] = bv[s]; redi[tid >> 4][s] = bi[s]; }
+        }
+        __syncthreads();
+        // ---- decision ---------------------------------------------------------------------------------------------------
+        if (tid < SPW && s_active[tid]) {
+            const int s = tid, b = b0 + s;
+            float best = -INFINITY;
+            int k = 0x7fffffff;
+            for (int g = 0; g < NTH / 16; ++g) {
+                const float v = redv[g][s];
+                const int ix = redi[g][s];
+                if (v > best || (v == best && ix < k)) { best = v; k = ix; }
+            }
+            if (k == p.blank) {
+                s_fidx[s] += 1;
+                s_nsym[s] = 0;
+                s_active[s] = 0;           // nothing to commit
+            } else {
+                const int cnt = s_count[s];
+                if (cnt < p.max_tokens) p.tokens[(long long)b * p.max_tokens + cnt] = k;
+                s_count[s] = cnt + 1;
+                s_tok[s] = k;
+                const int ns = s_nsym[s] + 1;
+                if (ns >= p.n_steps) { s_nsym[s] = 0; s_fidx[s] += 1; } else { s_nsym[s] = ns; }
+                s_active[s] = 2;           // commit flag
+            }
+        } else if (tid < SPW) {
+            s_active[tid] = 0;
+        }
+        __syncthreads();
+        for (int e = tid; e < SPW * RNNT_D; e += NTH) {   // commit (h', c') of the streams that emitted a symbol
+            const int s = e >> 8, j = e & 255;
+            if (s_active[s] == 2) { hs[s][j] = h2[s][j]; cs[s][j] = c2[s][j]; }
+        }
+        ++evals;
+        __syncthreads();
+    }
+    // ---- write the state back (buffer 0 becomes the committed one) ----------------------------------------------------
+    for (int e = tid; e < SPW * RNNT_D; e += NTH) {
+        const int s = e >> 8, j = e & 255, b = b0 + s;
+        if (b < p.B) {
+            stg1(p.h + (long long)b * RNNT_D + j, hs[s][j]);
+            stg1(p.c + (long long)b * RNNT_D + j, cs[s][j]);
+        }
+    }
+    if (tid < SPW && b0 + tid < p.B) {
+        const int b = b0 + tid;
+        p.sel[b] = 0;
+        p.tok[b] = s_tok[tid];
+        p.fidx[b] = s_fidx[tid];
+        p.nsym[b] = s_nsym[tid];
+        p.count[b] = s_count[tid];
+    }
+    if (tid == 0) atomicAdd(p.ctrl + 2, evals);
+}
+
+// packed argmax keys (EPI_ARGMAX) -> int32 indices (CTC head)
+__global__ void unpack_keys(const unsigned long long* __restrict__ key, int* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (int)(0xFFFFFFFFu - (unsigned)(key[i] & 0xFFFFFFFFull));
+}
+
+// frames_ready <- n (one thread; the kernel boundary before it released the encoder's writes)
+__global__ void publish_frames(int* ctrl, int n) {
+    __hip_atomic_store(ctrl, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------

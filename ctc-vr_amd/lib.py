@@ -37,6 +37,7 @@ SIGNATURES = {
     "rnnt_predictor_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rnnt_joint": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rnnt_encoder_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
+    "rnnt_ctc_argmax": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_get_att_cache": (c_i32, [c_vp, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_get_cnn_cache": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "rnnt_get_predictor_state": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32p, c_vp]),
@@ -206,6 +207,15 @@ class RnntEngine:
         self._chk(self.lib.rnnt_encoder_full(self.ctx, fbank_ptr, _np_ptr(lens), B, T, out_ptr, ctypes.byref(t), stream), "rnnt_encoder_full")
         self.n_streams = 0
         return t.value
+
+    def ctc_argmax(self, fbank_ptr, lens, B, T, stream=None):
+        lens = np.ascontiguousarray(lens, np.int32)
+        tq = ((T - 3) // 2 + 1 - 3) // 2 + 1
+        ids = np.zeros((B, tq), np.int32)
+        t = c_i32(0)
+        self._chk(self.lib.rnnt_ctc_argmax(self.ctx, fbank_ptr, _np_ptr(lens), B, T, _np_ptr(ids), ctypes.byref(t), stream), "rnnt_ctc_argmax")
+        self.n_streams = 0
+        return ids
 
     # ---- state read-back ----------------------------------------------------------------------
     def att_cache(self, b=0, stream=None):

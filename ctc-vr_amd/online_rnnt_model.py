@@ -291,6 +291,34 @@ class OnlineRNNTModel:
             return [max(self.streaming_beam_hypotheses, key=lambda h: h.log_prob).tokens], None, None     # :598-601
         return [[]], None, None
 
+    # ---- CTC head (model/online_rnnt_model.py:647-671) ---------------------------------------------------
+    def ctc_greedy_search(self, audios: torch.Tensor, audio_lens: torch.Tensor) -> List[List[int]]:
+        """Greedy CTC decode on the same encoder.  Deviation, on purpose: the reference calls `self.encoder(x, lens)`,
+        which in eval mode with use_dynamic_chunk draws a RANDOM chunk mask (wenet/utils/mask.py:170-183; SURVEY.md
+        §0.8: two identical calls differ by 0.61); this uses the deterministic full-context encoder
+        (decoding_chunk_size=-1).  Collapse rule as in :660-671: drop blanks and repeats over the valid frames.
+        Invalidates the streaming state of this object (the full-context pass reuses the conv rings)."""
+        if self.ctc_weight <= 0.0:
+            return [[] for _ in range(audios.size(0))]
+        self._require_loaded()
+        B, T = audios.size(0), audios.size(1)
+        x = audios.to(self.device, torch.float32).contiguous()
+        lens = audio_lens.detach().cpu().numpy().astype(np.int32)
+        ids = self._engine.ctc_argmax(x.data_ptr(), lens, B, T, _stream_ptr())
+        self._chunks_done = None
+        hyps = []
+        for b in range(B):
+            n1 = max(0, (min(int(lens[b]), T) - 1) // 2)          # valid frames after masks[:, :, 2::2][:, :, 2::2]
+            n = max(0, (n1 - 1) // 2)
+            hyp, prev = [], -1
+            for t in range(n):
+                tok = int(ids[b, t])
+                if tok != self.blank_id and tok != prev:
+                    hyp.append(tok)
+                prev = tok
+            hyps.append(hyp)
+        return hyps
+
     def forward(self, audios, audio_lens, texts=None, text_lens=None):
         if not self.streaming or texts is not None:
             raise NotImplementedError("training / offline forward is outside the accelerated path (SURVEY.md §8a: a4,a5 only)")

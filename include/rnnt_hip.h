@@ -155,6 +155,12 @@ int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32
 int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B,
                       int32_t T, float* out_dev, int32_t* frames_out, void* stream);
 
+/* CTC head on the same encoder: per-frame argmax of OnlineCTC.ctc_lo over the full-context encoder
+ * output (model/online_rnnt_model.py:37-38,655-658).  ids_host [B, T'] int32; the repeat/blank collapse (:660-671)
+ * is host code.  Needs ctc_head.ctc_lo.{weight,bias} among the loaded tensors. */
+int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                    int32_t* ids_host, int32_t* frames_out, void* stream);
+
 /* -- state read-back in the reference's layouts (parity tests, facade attributes) -------------- */
 /* streaming_att_cache of one stream: [12, 4, len, 128] (K = [...,:64], V = [...,64:],
  * wenet/transformer/encoder.py:284); *len_out = cached frames.  dst_host may be NULL to query len. */

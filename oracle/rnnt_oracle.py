@@ -208,6 +208,27 @@ def encoder_full(sd: SD, xs: Tensor, xs_lens: Tensor) -> Tuple[Tensor, Tensor]:
     return _ln(sd, "encoder.after_norm", x), masks
 
 
+def ctc_greedy_search_full(sd: SD, xs: Tensor, xs_lens: Tensor, blank: int) -> List[List[int]]:
+    """OnlineRNNTModel.ctc_greedy_search (model/online_rnnt_model.py:647-671) on the deterministic full-context
+    encoder (the reference's own call uses a random dynamic chunk mask in eval, SURVEY.md §0.8, so only this variant
+    can be pinned): argmax of log_softmax(ctc_lo(enc)) per frame, then drop blanks and repeats over the valid frames.
+    Parity note: pinned only through encoder_full (golden) + torch Linear/argmax; the reference has no fixture for it."""
+    enc, mask = encoder_full(sd, xs, xs_lens)
+    lp = torch.log_softmax(F.linear(enc, sd["ctc_head.ctc_lo.weight"], sd["ctc_head.ctc_lo.bias"]), dim=2)
+    am = torch.argmax(lp, dim=2)
+    hyps = []
+    for b in range(xs.size(0)):
+        n = int(mask[b].squeeze().sum().item())
+        hyp, prev = [], -1
+        for t in range(n):
+            tok = int(am[b, t])
+            if tok != blank and tok != prev:
+                hyp.append(tok)
+            prev = tok
+        hyps.append(hyp)
+    return hyps
+
+
 # --------------------------------------------------------------------------------------
 # predictor / joint
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,81 @@
+"""Host half of the beam search (ctc_vr_amd.online_rnnt_model.beam_advance_frame: candidate order, Python-double
+scores, stable sort, first-wins de-dup, state-slot selection) checked on CPU against the reference's golden beams.
+The device half (rnnt_beam_frame / rnnt_beam_select) is emulated here with the oracle's predictor/joint, following the
+contract in include/rnnt_hip.h, so a disagreement can only come from the host logic."""
+import numpy as np
+import pytest
+import torch
+
+import ctc_vr_amd.testing as T
+from conftest import load_golden
+from ctc_vr_amd.online_rnnt_model import BeamHypothesis, beam_advance_frame
+from oracle import rnnt_oracle as O
+
+
+class FakeEngine:
+    """rnnt_beam_frame / rnnt_beam_select semantics on torch-CPU (state pool [rows][n_steps+1] of (h, c))."""
+
+    class Cfg:
+        vocab_size = T.VOCAB
+        n_steps = 10
+
+    def __init__(self, sd, blank):
+        self.sd, self.blank, self.cfg = sd, blank, self.Cfg()
+        z = O.predictor_init_state(1)
+        self.rows = [[(z[0].clone(), z[1].clone())]]     # row 0: zero state (fresh stream)
+        self.enc = None
+
+    def beam_frame(self, frame_idx, row_stream, row_tok, k, stream=None):
+        n, ns = len(row_stream), self.cfg.n_steps
+        steps = np.zeros(n, np.int32)
+        blank_lp = np.zeros((n, ns), np.float32)
+        top_lp = np.zeros((n, ns, k), np.float32)
+        top_tok = np.zeros((n, ns, k), np.int32)
+        enc_t = self.enc[:, frame_idx:frame_idx + 1]
+        for r in range(n):
+            pool = [self.rows[r][0]]
+            tok = row_tok[r]
+            for st in range(ns):
+                out, nxt = O.predictor_step(self.sd, torch.tensor([[tok]]), [pool[st][0], pool[st][1]])
+                pool.append((nxt[0], nxt[1]))
+                logp = torch.log_softmax(O.joint(self.sd, enc_t, out).squeeze(), dim=-1)
+                blank_lp[r, st] = logp[self.blank].item()
+                nb = logp.clone()
+                nb[self.blank] = -float("inf")
+                v, i = torch.topk(nb, k)
+                top_lp[r, st], top_tok[r, st] = v.numpy(), i.numpy()
+                steps[r] = st + 1
+                if float(blank_lp[r, st]) >= float(logp.max().item()) - 1e-6:
+                    break
+                tok = int(i[0])
+            self.rows[r] = pool
+        return steps, blank_lp, top_lp, top_tok
+
+    def beam_select(self, src_row, src_step, stream=None):
+        self.rows = [[self.rows[r][s]] for r, s in zip(src_row, src_step)]
+
+
+@pytest.mark.parametrize("name", ["beam_ex6_c16_s0", "beam_syn0_c16_s1_f320"])
+def test_host_beam_logic_matches_reference(name, np_state_dict):
+    g = load_golden(f"{name}.npz")
+    sd = O.to_torch_sd(np_state_dict(int(g["seed"])))
+    src = name[5:].split("_")[0]
+    if src.startswith("syn"):
+        x = torch.from_numpy(T.synth_fbank(2, 1000))[0:1, :int(g["frames"])]
+    else:
+        gi = load_golden("inputs_example1.npz")
+        x = torch.from_numpy(gi[src])[None]
+    chunk, beam_size = int(g["chunk"]), int(g["beam"])
+    eng = FakeEngine(sd, T.BLANK)
+    att, cnn = torch.zeros(0, 0, 0, 0), torch.zeros(0, 0, 0, 0)
+    beam, off = [BeamHypothesis([], 0.0)], 0
+    for ci, (a, b) in enumerate(T.chunk_plan(x.shape[1], chunk)):
+        enc, att, cnn = O.forward_chunk(sd, x[:, a:b], off, off, att, cnn)
+        off += (b - a) // 4
+        eng.enc = enc
+        for t in range(enc.size(1)):
+            beam = beam_advance_frame(eng, t, [beam], T.BLANK, beam_size)[0]
+        assert len(beam) == int(g[f"c{ci}_n"]), ci
+        for hi, h in enumerate(beam):
+            assert h.tokens == g[f"c{ci}_h{hi}_tokens"].tolist(), (ci, hi)
+            assert abs(h.log_prob - float(g[f"c{ci}_h{hi}_logp"])) < 1e-3

@@ -273,6 +273,30 @@ def test_encoder_full_context(models):
     del eng
 
 
+def test_ctc_greedy_search_against_oracle(models, np_state_dict):
+    """CTC head on the full-context encoder vs the oracle (argmax exact, collapse rule)."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_model import OnlineRNNTModel
+    m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=T.VOCAB, blank_id=T.BLANK, max_streams=2, max_chunk_frames=320,
+                        max_cache_frames=128, max_enc_frames=128, max_beam=0)
+    m.load_state_dict(np_state_dict(0))
+    x = torch.from_numpy(T.synth_fbank(2, 300, seed=99))
+    lens = torch.tensor([300, 203])
+    got = m.ctc_greedy_search(x, lens)
+    want = O.ctc_greedy_search_full(O.to_torch_sd(np_state_dict(0)), x, lens, T.BLANK)
+    assert got == want and len(got[0]) > 0
+
+
+def test_rtf_harness(models):
+    """per-chunk RTF statistics with online_rnnt_delay.py's definition."""
+    from ctc_vr_amd.online_rnnt_delay import evaluate_rtf
+    m = models(0, 16)
+    ex = ex_inputs()
+    r = evaluate_rtf(m, [ex["ex6"][0]], 16, beam_size=4)
+    assert r["greedy"]["chunks"] == 10 and r["beam"]["chunks"] == 10
+    assert 0 < r["greedy"]["p50"] <= r["greedy"]["max"] and r["greedy"]["mean"] < 1.0   # faster than real time
+
+
 def test_error_paths(models):
     from ctc_vr_amd.lib import RnntEngine, RnntError
     m = models(0, 16)

@@ -18,9 +18,9 @@ template <int WK, int MT, int NT> void launch_tab(hipStream_t s, const GemmP* ta
     dim3 grid((N + 16 * NT - 1) / (16 * NT), (M + 16 * MT - 1) / (16 * MT), n);
     hipLaunchKernelGGL((gemm16_tab<WK, MT, NT>), grid, dim3(64 * WK), 0, s, tab);
 }
-template <int MT, int NT> void launch_ns(hipStream_t s, const GemmP* tab, int n, int M, int N) {
+template <int MT, int NT, int BK = 32> void launch_ns(hipStream_t s, const GemmP* tab, int n, int M, int N) {
     const int ntn = (N + 32 * NT - 1) / (32 * NT), ntm = (M + 32 * MT - 1) / (32 * MT);
-    hipLaunchKernelGGL((gemm_ns_tab<MT, NT>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab, n, ntn, ntm);
+    hipLaunchKernelGGL((gemm_ns_tab<MT, NT, BK>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab, n, ntn, ntm);
 }
 static double time_eager(hipStream_t s, int iters, const std::function<void(hipStream_t)>& f) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -80,13 +80,18 @@ int main() {
         snprintf(nm, 64, "ffn1 ln=%d NS<2,2> (64x64)", ln); run(nm, F1, [&](hipStream_t st) { launch_ns<2, 2>(st, tab, G, M, 1024); });
         snprintf(nm, 64, "ffn1 ln=%d NS<1,2> (32x64)", ln); run(nm, F1, [&](hipStream_t st) { launch_ns<1, 2>(st, tab, G, M, 1024); });
         snprintf(nm, 64, "ffn1 ln=%d NS<2,4> (64x128)", ln); run(nm, F1, [&](hipStream_t st) { launch_ns<2, 4>(st, tab, G, M, 1024); });
+        snprintf(nm, 64, "ffn1 ln=%d NS<1,2> BK64", ln); run(nm, F1, [&](hipStream_t st) { launch_ns<1, 2, 64>(st, tab, G, M, 1024); });
+        snprintf(nm, 64, "ffn1 ln=%d NS<2,2> BK64", ln); run(nm, F1, [&](hipStream_t st) { launch_ns<2, 2, 64>(st, tab, G, M, 1024); });
     }
     fill(256, 1024, false, EPI_RESID, G);
     run("ffn2 N256 K1024 NS<1,2> (32x64)", F1, [&](hipStream_t st) { launch_ns<1, 2>(st, tab, G, M, 256); });
     run("ffn2 N256 K1024 NS<2,2> (64x64)", F1, [&](hipStream_t st) { launch_ns<2, 2>(st, tab, G, M, 256); });
+    run("ffn2 N256 K1024 NS<1,2> BK64", F1, [&](hipStream_t st) { launch_ns<1, 2, 64>(st, tab, G, M, 256); });
+    run("ffn2 N256 K1024 NS<1,1> BK64", F1, [&](hipStream_t st) { launch_ns<1, 1, 64>(st, tab, G, M, 256); });
     run("ffn2 N256 K1024 NS<1,1> (32x32)", F1, [&](hipStream_t st) { launch_ns<1, 1>(st, tab, G, M, 256); });
     fill(256, 256, false, EPI_RESID, G);
     run("out N256 K256 NS<1,2> (32x64)", 2.0 * G * M * 256 * 256, [&](hipStream_t st) { launch_ns<1, 2>(st, tab, G, M, 256); });
+    run("out N256 K256 NS<1,1> BK64", 2.0 * G * M * 256 * 256, [&](hipStream_t st) { launch_ns<1, 1, 64>(st, tab, G, M, 256); });
     run("out N256 K256 NS<1,1> (32x32)", 2.0 * G * M * 256 * 256, [&](hipStream_t st) { launch_ns<1, 1>(st, tab, G, M, 256); });
     for (int dbg : {7}) {
         DBG = dbg;
