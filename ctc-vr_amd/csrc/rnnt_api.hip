@@ -62,8 +62,10 @@ struct rnnt_ctx {
     float *h = nullptr, *c = nullptr, *pred = nullptr, *z = nullptr, *logits = nullptr;
     int *tok = nullptr, *fidx = nullptr, *nsym = nullptr, *count = nullptr, *tokens = nullptr, *n_active = nullptr, *klen = nullptr, *sel = nullptr;
     unsigned long long* key = nullptr;
-    int* dec_ctrl = nullptr;   // persistent decoder control block: [0] frames_ready, [1] error, [2] evaluations
+    int* dec_ctrl = nullptr;   // persistent decoder control block: [0] frames_ready, [1] error, [2] evaluations, [3..6] cooperative decoder
     int use_persistent = 1;
+    int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
+    float* coop_z = nullptr; int* coop_st2 = nullptr; unsigned long long* coop_key2 = nullptr;
     const float *wjc = nullptr, *bjc = nullptr;   // folded joint.pred_ffn o predictor.projection
     const float *wctc = nullptr, *bctc = nullptr; // ctc_head.ctc_lo (optional)
     // beam search: state pools [rows][n_steps+1][512] (ping-pong), per-row buffers
@@ -529,6 +531,23 @@ int greedy_drain(rnnt_ctx* ctx, hipStream_t s, int n_frames, int done_steps) {
 // Persistent greedy decoder: one resident workgroup per 2 streams decodes every frame up to n_total, waiting on
 // dec_ctrl[0] (frames_ready).  The control block must have been initialised on a stream this one is ordered after.
 int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total) {
+    if (ctx->use_coop && ctx->n_streams <= 64) {
+        // cooperative decoder: 64 resident workgroups, weights stationary in LDS, 3 grid barriers per evaluation
+        CoopP c;
+        memset(&c, 0, sizeof(c));
+        c.whh = ctx->whh_il; c.egate = ctx->egate; c.wjc = ctx->wjc; c.bjc = ctx->bjc; c.wout = ctx->wout; c.bout = ctx->bout;
+        c.encp = ctx->encp; c.h = ctx->h; c.c = ctx->c; c.z = ctx->coop_z; c.sel = ctx->sel; c.tok = ctx->tok; c.fidx = ctx->fidx;
+        c.nsym = ctx->nsym; c.count = ctx->count; c.tokens = ctx->tokens; c.st2 = ctx->coop_st2; c.key2 = ctx->coop_key2; c.ctrl = ctx->dec_ctrl;
+        c.fstride_f = (long long)ctx->fstride * D; c.bstride = (long long)ctx->cfg.max_streams * D;
+        c.B = ctx->n_streams; c.vocab = ctx->cfg.vocab_size; c.blank = ctx->cfg.blank_id; c.n_steps = ctx->cfg.n_steps;
+        c.max_tokens = ctx->cfg.max_tokens; c.n_total = n_total;
+        c.timeout_ticks = 300000000ll;   // 3 s per barrier spin (100 MHz counter)
+        static const bool cdbg = getenv("RNNT_COOP_DBG") != nullptr;
+        c.dbg = cdbg ? reinterpret_cast<long long*>(ctx->coop_z + 64 * D) : nullptr;
+        hipLaunchKernelGGL(greedy_coop, dim3(COOP_G), dim3(256), 0, s, c);
+        LAUNCHCHK("greedy_coop");
+        return RNNT_OK;
+    }
     DecP d;
     memset(&d, 0, sizeof(d));
     d.whh = ctx->whh_il; d.egate = ctx->egate; d.wjc = ctx->wjc; d.bjc = ctx->bjc; d.wout = ctx->wout; d.bout = ctx->bout;
@@ -541,7 +560,12 @@ int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total) {
     static const int dth = getenv("RNNT_DEC_THREADS") ? atoi(getenv("RNNT_DEC_THREADS")) : 512;   // 1 stream / 512 threads: no spills,
     static const int spw = getenv("RNNT_DEC_SPW") ? atoi(getenv("RNNT_DEC_SPW")) : 1;             // best of the measured variants
     const int B = ctx->n_streams;
-    if (spw == 1) {
+    static const int kf = getenv("RNNT_DEC_KF") ? atoi(getenv("RNNT_DEC_KF")) : 4;   // frames per vocabulary pass (0: old kernel)
+    if (kf == 1) hipLaunchKernelGGL(greedy_stream<1>, dim3(B), dim3(512), 0, s, d);
+    else if (kf == 2) hipLaunchKernelGGL(greedy_stream<2>, dim3(B), dim3(512), 0, s, d);
+    else if (kf == 4) hipLaunchKernelGGL(greedy_stream<4>, dim3(B), dim3(512), 0, s, d);
+    else if (kf == 8) hipLaunchKernelGGL(greedy_stream<8>, dim3(B), dim3(512), 0, s, d);
+    else if (spw == 1) {
         if (dth == 512) hipLaunchKernelGGL((greedy_persistent<1, 512>), dim3(B), dim3(512), 0, s, d);
         else hipLaunchKernelGGL((greedy_persistent<1, 1024>), dim3(B), dim3(1024), 0, s, d);
     } else if (spw == 4) {
@@ -556,7 +580,13 @@ int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total) {
 }
 
 int init_decoder_ctrl(rnnt_ctx* ctx, hipStream_t s, int frames_ready) {
-    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->dec_ctrl, 0, 8LL);
+    if (ctx->use_coop && ctx->n_streams <= 64) {
+        hipLaunchKernelGGL(coop_init, dim3(1), dim3(64), 0, s, ctx->coop_st2, ctx->coop_key2, ctx->dec_ctrl, ctx->tok, ctx->fidx, ctx->nsym,
+                           ctx->sel, ctx->count, ctx->n_streams, frames_ready);
+        LAUNCHCHK("coop_init");
+        return RNNT_OK;
+    }
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->dec_ctrl, 0, 32LL);
     LAUNCHCHK("fill_i32");
     hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, frames_ready);
     LAUNCHCHK("publish_frames");
@@ -568,7 +598,14 @@ int finish_persistent_decoder(rnnt_ctx* ctx, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(ctx->pinned + 12, ctx->dec_ctrl, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->greedy_steps += ctx->pinned[14];
-    if (ctx->pinned[13] != 0) return fail(ctx, RNNT_ERR_STATE, "persistent decoder timed out waiting for encoder frames");
+    if (getenv("RNNT_COOP_DBG") && ctx->use_coop && ctx->n_streams <= 64) {
+        long long t[8];
+        (void)hipMemcpy(t, ctx->coop_z + 64 * D, sizeof(t), hipMemcpyDeviceToHost);
+        const double ev = ctx->pinned[14] > 0 ? ctx->pinned[14] : 1;
+        fprintf(stderr, "[coop] evals %d; us/eval: decide %.2f, L %.2f, bar1 %.2f, J %.2f, bar2 %.2f, O %.2f, bar3 %.2f\n", ctx->pinned[14],
+                t[0] / ev / 100.0, t[1] / ev / 100.0, t[2] / ev / 100.0, t[3] / ev / 100.0, t[4] / ev / 100.0, t[5] / ev / 100.0, t[6] / ev / 100.0);
+    }
+    if (ctx->pinned[13] != 0) return fail(ctx, RNNT_ERR_STATE, "persistent decoder gave up (code %d: 1 = frame wait, 2 = barrier, 3 = idle bound)", ctx->pinned[13]);
     return RNNT_OK;
 }
 
@@ -603,6 +640,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     HIPCHK(hipSetDevice(cfg->device));
     if (const char* ng = getenv("RNNT_NO_GRAPH")) ctx->use_graphs = (ng[0] == '1') ? 0 : 1;
     if (const char* pe = getenv("RNNT_PERSISTENT")) ctx->use_persistent = (pe[0] == '0') ? 0 : 1;
+    if (const char* ce = getenv("RNNT_COOP")) ctx->use_coop = (ce[0] == '0') ? 0 : 1;
     const int B = cfg->max_streams;
     ctx->tmax = sub_len(cfg->max_chunk_frames);
     ctx->t1max = sub1_len(cfg->max_chunk_frames);
@@ -630,7 +668,8 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     ALLOC(h, (size_t)2 * B * D); ALLOC(c, (size_t)2 * B * D); ALLOC(sel, B); ALLOC(key, B);
     ALLOC(pred, (size_t)B * D); ALLOC(z, (size_t)B * D); ALLOC(logits, (size_t)B * ctx->vpad);
     ALLOC(tok, B); ALLOC(fidx, B); ALLOC(nsym, B); ALLOC(count, B); ALLOC(tokens, (size_t)B * cfg->max_tokens);
-    ALLOC(n_active, 4); ALLOC(klen, B); ALLOC(dec_ctrl, 8);
+    ALLOC(n_active, 4); ALLOC(klen, B); ALLOC(dec_ctrl, 32);
+    ALLOC(coop_z, 64 * D + 64); ALLOC(coop_st2, 2 * 5 * 64); ALLOC(coop_key2, 2 * 64);
     if (cfg->max_beam > 0) {
         ctx->max_rows = B * cfg->max_beam;
         const size_t R = ctx->max_rows, NS = cfg->n_steps, KB = cfg->max_beam;
@@ -652,7 +691,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
 void rnnt_destroy(rnnt_ctx* ctx) {
     if (!ctx) return;
     void* ptrs[] = {ctx->blob, ctx->egate, ctx->y1, ctx->y2, ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf, ctx->kcache, ctx->vcache,
-                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->dec_ctrl, ctx->pred, ctx->z, ctx->logits,
+                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->dec_ctrl, ctx->coop_z, ctx->coop_st2, ctx->coop_key2, ctx->pred, ctx->z, ctx->logits,
                     ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch,
                     ctx->pool[0], ctx->pool[1], ctx->bpred, ctx->bz, ctx->blogits, ctx->b_blank, ctx->b_toplp, ctx->b_toptok,
                     ctx->b_tok, ctx->b_frame, ctx->b_active, ctx->b_steps, ctx->b_srcrow, ctx->b_srcstep};
@@ -1215,7 +1254,10 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     if (frames_out) *frames_out = fb - fb0;
     ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
     if (greedy && ctx->use_persistent) {
+        double t_e = 0;
+        if (timing) { (void)hipStreamSynchronize(s); t_e = now(); }
         if ((rc = finish_persistent_decoder(ctx, s2))) return rc;      // synchronises the decode stream (=> encoder done too)
+        if (timing) fprintf(stderr, "[rnnt timing] decoder finished %.3f ms after the encoder stream drained\n", now() - t_e);
         ctx->frames_decoded = fb;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));
         HIPCHK(hipStreamWaitEvent(caller ? caller : s, ctx->wf_ev[C], 0));

@@ -1434,10 +1434,467 @@ __global__ __launch_bounds__(NTH) void greedy_persistent(DecP p) {
     if (tid == 0) atomicAdd(p.ctrl + 2, evals);
 }
 
+// ------------------------------------------------------------------------------------------------
+// greedy_stream<KF>: resident greedy decoder, one workgroup (512 threads) per stream, exploiting two facts of the
+// reference's loop (online_rnnt_model.py:193-220) that make most of its evaluations redundant:
+//   (1) a blank leaves (token, h, c) unchanged, so the predictor output -- and with it W_c h' + b_c, the predictor half
+//       of the joint -- only changes when a symbol is emitted: the LSTM (1 MB of W_hh) and the folded projection (256 KB)
+//       are recomputed only then ("dirty");
+//   (2) while the predictor half is fixed, frames t, t+1, ... are independent of each other: KF frames go through the
+//       vocabulary projection in ONE pass over W_out (412 KB), and the decisions are scanned in order -- blanks advance
+//       the frame, the first non-blank emits, commits (h', c') and ends the scan (later frames' logits are discarded).
+// The results are those of the sequential loop (same operands and summation order per logit).  The dependent chain is
+// (#symbols) x (L + Jc + O) + (#blank runs / KF) x O instead of (#symbols + #frames) x (L + Jc + O).
+// ------------------------------------------------------------------------------------------------
+template <int KF>
+__global__ __launch_bounds__(512) void greedy_stream(DecP p) {
+    constexpr int NTH = 512;
+    __shared__ __attribute__((aligned(16))) float hs[1][RNNT_D], cs[RNNT_D], h2[1][RNNT_D], c2[RNNT_D], pp[RNNT_D];
+    __shared__ __attribute__((aligned(16))) float zs[KF][RNNT_D];
+    __shared__ __attribute__((aligned(16))) float gates[4 * RNNT_D];
+    __shared__ float redv[NTH / 16][KF];
+    __shared__ int redi[NTH / 16][KF];
+    __shared__ int s_ctl[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b >= p.B) return;
+    {
+        const long long off = (long long)(ldgi(p.sel + b) & 1) * p.bstride + (long long)b * RNNT_D;
+        if (tid < RNNT_D) { hs[0][tid] = ldg1(p.h + off + tid); cs[tid] = ldg1(p.c + off + tid); }
+    }
+    int tok = ldgi(p.tok + b), fidx = ldgi(p.fidx + b), nsym = ldgi(p.nsym + b), count = ldgi(p.count + b);   // uniform
+    int evals = 0, seen_ready = 0;
+    bool dirty = true;
+    const float* encp = p.encp + (long long)b * p.fstride_f;
+    __syncthreads();
+    while (fidx < p.n_total) {
+        // ---- frames available to this stream (bounded wait) ------------------------------------------------------------
+        if (tid == 0) {
+            int nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+            int err = 0;
+            while (nf <= fidx) {
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                    __hip_atomic_store(p.ctrl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    err = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+                nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (nf > seen_ready) {   // ONE acquire per publication: nobody reads stale enc_proj lines
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                seen_ready = nf;
+            }
+            s_ctl[0] = err;
+            s_ctl[1] = nf;
+        }
+        __syncthreads();
+        if (s_ctl[0]) break;
+        // frames evaluated together: right after a symbol only the current frame (more symbols are likely on it and the
+        // single-frame pass is cheaper), otherwise up to KF
+        const int kf = dirty ? 1 : min(KF, min(s_ctl[1], p.n_total) - fidx);
+        if (dirty) {
+            // ---- predictor step: gates = E[tok] + W_hh h; candidate (h', c'); pp = W_c h' + b_c ---------------------------
+            dec_matvec<1, NTH>(p.whh, 4 * RNNT_D, hs, [&](int n, const float* acc) {
+                gates[n] = acc[0] + ldg1(p.egate + (long long)tok * (4 * RNNT_D) + n);
+            });
+            __syncthreads();
+            if (tid < RNNT_D) {
+                const float4 gt = *reinterpret_cast<const float4*>(&gates[4 * tid]);
+                const float cc = sigmoidf_(gt.y) * cs[tid] + sigmoidf_(gt.x) * tanhf(gt.z);
+                c2[tid] = cc;
+                h2[0][tid] = sigmoidf_(gt.w) * tanhf(cc);
+            }
+            __syncthreads();
+            dec_matvec<1, NTH>(p.wjc, RNNT_D, h2, [&](int n, const float* acc) { pp[n] = acc[0] + ldg1(p.bjc + n); });
+            dirty = false;
+            __syncthreads();
+        }
+        // ---- joint activations of kf frames --------------------------------------------------------------------------------
+        for (int e = tid; e < (kf == 1 ? 1 : KF) * RNNT_D; e += NTH) {
+            const int k = e >> 8, n = e & 255;
+            zs[k][n] = k < kf ? tanhf(pp[n] + ldg1(encp + (long long)(fidx + k) * RNNT_D + n)) : 0.f;
+        }
+        __syncthreads();
+        // ---- vocabulary projection of the kf frames + per-frame argmax (first index on ties) ----------------------------------
+        float bv[KF];
+        int bi[KF];
+#pragma unroll
+        for (int k = 0; k < KF; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
+        if (KF > 1 && kf == 1) {
+            dec_matvec<1, NTH>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
+                const float v = acc[0] + ldg1(p.bout + n);
+                if (v > bv[0]) { bv[0] = v; bi[0] = n; }
+            });
+        } else {
+            dec_matvec<KF, NTH>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
+                const float bo = ldg1(p.bout + n);
+#pragma unroll
+                for (int k = 0; k < KF; ++k) {
+                    const float v = acc[k] + bo;
+                    if (v > bv[k]) { bv[k] = v; bi[k] = n; }
+                }
+            });
+        }
+        if ((tid & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < KF; ++k) { redv[tid >> 4][k] = bv[k]; redi[tid >> 4][k] = bi[k]; }
+        }
+        __syncthreads();
+        // ---- decisions, in frame order (every thread computes the same uniform result) -----------------------------------------
+        {
+            const int k = tid >> 6 < KF ? tid >> 6 : 0;     // wave k reduces frame k (waves >= KF idle)
+            const int ln = tid & 63;
+            float best = -INFINITY;
+            int ix = 0x7fffffff;
+            if (ln < NTH / 16) { best = redv[ln][k]; ix = redi[ln][k]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(ix, o, 64);
+                if (ov > best || (ov == best && oi < ix)) { best = ov; ix = oi; }
+            }
+            __syncthreads();                                  // redi fully read before it is reused for the winners
+            if (ln == 0 && (tid >> 6) < KF) redi[0][tid >> 6] = ix;
+        }
+        __syncthreads();
+        bool commit = false;
+        for (int k = 0; k < kf; ++k) {
+            const int w = redi[0][k];
+            if (w == p.blank) { fidx += 1; nsym = 0; continue; }
+            if (tid == 0 && count < p.max_tokens) p.tokens[(long long)b * p.max_tokens + count] = w;
+            count += 1;
+            tok = w;
+            nsym += 1;
+            if (nsym >= p.n_steps) { nsym = 0; fidx += 1; }
+            commit = true;
+            break;
+        }
+        if (commit) {
+            if (tid < RNNT_D) { hs[0][tid] = h2[0][tid]; cs[tid] = c2[tid]; }
+            dirty = true;
+        }
+        ++evals;
+        __syncthreads();
+    }
+    // ---- write the state back (buffer 0 becomes the committed one) ----------------------------------------------------
+    if (tid < RNNT_D) {
+        stg1(p.h + (long long)b * RNNT_D + tid, hs[0][tid]);
+        stg1(p.c + (long long)b * RNNT_D + tid, cs[tid]);
+    }
+    if (tid == 0) {
+        p.sel[b] = 0; p.tok[b] = tok; p.fidx[b] = fidx; p.nsym[b] = nsym; p.count[b] = count;
+        atomicAdd(p.ctrl + 2, evals);
+    }
+}
+
 // packed argmax keys (EPI_ARGMAX) -> int32 indices (CTC head)
 __global__ void unpack_keys(const unsigned long long* __restrict__ key, int* __restrict__ out, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         out[i] = (int)(0xFFFFFFFFu - (unsigned)(key[i] & 0xFFFFFFFFull));
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy_coop: cooperative, weights-STATIONARY greedy decoder for B <= 64 streams.  64 resident workgroups; workgroup
+// g keeps rows [16g,16g+16) of W_hh (all 64), of the folded joint matrix W_c (g < 16) and of W_out (g < 26) in LDS for
+// the whole call, so an evaluation moves only activations: every workgroup computes its 16 output columns for ALL
+// streams with exact-f32 MFMAs (M = 64 streams), and the three dependent products of an evaluation
+//     gates = E[tok] + h W_hh^T  ->  z = tanh(enc_proj[t] + h' W_c^T + b_c)  ->  logits = z W_out^T + b_out -> argmax
+// are separated by three grid-wide counter barriers.  The per-stream persistent kernel above streams 1.7 MB of
+// weights per evaluation from L2 (~23 us at the ~70 GB/s one CU gets, and it thrashes the L2 the encoder needs);
+// here nothing but ~200 KB of activations crosses L2 per evaluation.
+// Inter-workgroup protocol (guide, Guideline 16 R1): every exchanged word is written with a relaxed agent-scope atomic
+// store (write-through, sc1), every storing wave drains vmcnt before the workgroup arrives at the barrier (one
+// agent-scope atomic add), the poller spins on a relaxed agent-scope load, and every exchanged word is read with
+// relaxed agent-scope atomic loads (bypass the non-coherent L1).  All spins are bounded by the wall clock; a timeout
+// or an abort raised by another workgroup makes every workgroup leave.
+// ------------------------------------------------------------------------------------------------
+struct CoopP {
+    const float* whh; const float* egate; const float* wjc; const float* bjc; const float* wout; const float* bout;
+    const float* encp;
+    float* h; float* c;          // [2][bstride] state buffers
+    float* z;                    // [64][256] exchange buffer for the joint activations
+    int* sel; int* tok; int* fidx; int* nsym; int* count; int* tokens;
+    int* st2;                    // [2][5][64] ping-pong copy of (tok, fidx, nsym, sel, count) by evaluation parity
+    unsigned long long* key2;    // [2][64] packed argmax by evaluation parity
+    int* ctrl;                   // [0] frames_ready, [1] error, [2] evaluations, [3] barrier counter, [4] abort, [5..6] nf by parity
+    long long fstride_f, bstride;
+    int B, vocab, blank, n_steps, max_tokens, n_total;
+    long long timeout_ticks;
+    long long* dbg;              // optional [8] phase timers (100 MHz ticks, workgroup 0), null = off
+};
+
+__device__ __forceinline__ float ld_sc1f(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1f(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_sc1i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#define COOP_G 64      // workgroups: 4 stream groups x 16 column groups
+#define COOP_CG 16
+#define COOP_LD 260
+// barrier among the 16 workgroups of one stream group; returns false when the launch must be abandoned
+__device__ __forceinline__ bool coop_barrier(const CoopP& p, int* counter, int target, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        while (ld_sc1i(counter) < target) {
+            if (ld_sc1i(p.ctrl + 4) != 0) { ok = 0; break; }
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                st_sc1i(p.ctrl + 1, 2);
+                st_sc1i(p.ctrl + 4, 1);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// stage the 16 rows of my stream group (256 floats each) into X[16][COOP_LD] with sc1 loads, all issued before any store
+template <typename RowOff>
+__device__ __forceinline__ void coop_stage(float* X, const float* base, int nrows, RowOff row_off) {
+    const int tid = threadIdx.x;
+    unsigned long long v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j;
+        const int r = e >> 7, c2 = (e & 127) * 2;
+        v[j] = 0ull;
+        if (r < nrows) v[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(base + row_off(r) + c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j;
+        *reinterpret_cast<unsigned long long*>(&X[(e >> 7) * COOP_LD + (e & 127) * 2]) = v[j];
+    }
+}
+
+// 2-D partition: workgroup g = sg * 16 + cg owns streams [16 sg, 16 sg + 16) and, of every weight matrix, the rows of
+// column group cg: W_hh rows [64 cg, +64) (16 hidden units x 4 gates), W_c rows [16 cg, +16), W_out rows [26 cg, +26).
+// A workgroup therefore gathers only ITS 16 streams' activations (16 KB per phase) and synchronises only with the 15
+// workgroups of its stream group; the 4 stream groups advance independently.
+// ctrl: [0] frames_ready [1] error [2] evaluations [4] abort [8+sg] barrier counters [16 + 2 sg + par] frames seen by group sg
+__global__ __launch_bounds__(256) void greedy_coop(CoopP p) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * COOP_LD], Wj[16 * COOP_LD], Wo[32 * COOP_LD];
+    __shared__ __attribute__((aligned(16))) float X[16 * COOP_LD];
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    __shared__ int s_tok[16], s_fidx[16], s_nsym[16], s_sel[16], s_count[16], s_act[16];
+    __shared__ int s_flag, s_done, s_nf, s_any;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sg = blockIdx.x / COOP_CG, cg = blockIdx.x % COOP_CG;
+    const int i = lane & 15, kq = lane >> 4;
+    const int b0 = 16 * sg;
+    const int nb = min(16, p.B - b0);        // streams of my group (<= 0: the group has nothing to do)
+    if (nb <= 0) return;                      // whole stream group absent: all its 16 workgroups leave
+    // ---- resident weight slices ---------------------------------------------------------------------------------------
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c4 = (e & 63) * 4;
+        *reinterpret_cast<float4*>(&Wl[r * COOP_LD + c4]) = ldg4(p.whh + (long long)(64 * cg + r) * RNNT_D + c4);
+        if (r < 16) *reinterpret_cast<float4*>(&Wj[r * COOP_LD + c4]) = ldg4(p.wjc + (long long)(16 * cg + r) * RNNT_D + c4);
+        if (r < 32) *reinterpret_cast<float4*>(&Wo[r * COOP_LD + c4]) = ldg4(p.wout + (long long)min(26 * cg + min(r, 25), p.vocab - 1) * RNNT_D + c4);
+    }
+    int* bar_ctr = p.ctrl + 8 + sg;
+    int bar = 0, seen_nf = 0, evals = 0;
+    const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = t_start;
+#define COOP_T(k) { if (p.dbg && blockIdx.x == 0 && tid == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tl; tl = t_; } }
+    __syncthreads();
+    for (int ev = 0;; ++ev) {
+        const int par = ev & 1;
+        int* st_in = p.st2 + par * 5 * 64;
+        int* st_out = p.st2 + (par ^ 1) * 5 * 64;
+        // ---- D: apply the previous argmax of my 16 streams (all 16 workgroups of the group recompute; cg == 0 records) --
+        if (tid < 16) {
+            const int b = b0 + tid;
+            int tokv = p.blank, f = p.n_total, ns = 0, sl = 0, cnt = 0, act = 0;
+            const int nf = ld_sc1i(p.ctrl + 16 + 2 * sg + par);
+            if (tid < nb) {
+                tokv = ld_sc1i(st_in + 0 * 64 + b); f = ld_sc1i(st_in + 1 * 64 + b); ns = ld_sc1i(st_in + 2 * 64 + b);
+                sl = ld_sc1i(st_in + 3 * 64 + b); cnt = ld_sc1i(st_in + 4 * 64 + b);
+                const unsigned long long k64 = __hip_atomic_load(p.key2 + par * 64 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k64 != 0ull) {
+                    const int k = (int)(0xFFFFFFFFu - (unsigned)(k64 & 0xFFFFFFFFull));
+                    if (k == p.blank) { f += 1; ns = 0; }
+                    else {
+                        if (cg == 0 && cnt < p.max_tokens) p.tokens[(long long)b * p.max_tokens + cnt] = k;
+                        cnt += 1; tokv = k; sl ^= 1; ns += 1;
+                        if (ns >= p.n_steps) { ns = 0; f += 1; }
+                    }
+                }
+                act = f < nf ? 1 : 0;
+                if (cg == 0) {
+                    st_sc1i(st_out + 0 * 64 + b, tokv); st_sc1i(st_out + 1 * 64 + b, f); st_sc1i(st_out + 2 * 64 + b, ns);
+                    st_sc1i(st_out + 3 * 64 + b, sl); st_sc1i(st_out + 4 * 64 + b, cnt);
+                    __hip_atomic_store(p.key2 + (par ^ 1) * 64 + b, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            s_tok[tid] = tokv; s_fidx[tid] = f; s_nsym[tid] = ns; s_sel[tid] = sl; s_count[tid] = cnt; s_act[tid] = act;
+            const unsigned long long m16 = 0xFFFFull;
+            const unsigned long long anyact = __ballot(act != 0) & m16, notdone = __ballot(tid < nb && f < p.n_total) & m16;
+            if (tid == 0) { s_done = notdone == 0ull ? 1 : 0; s_nf = nf; s_any = anyact != 0ull ? 1 : 0; }
+        }
+        __syncthreads();
+        COOP_T(0)
+        if (s_done) break;
+        const bool anyact = s_any != 0;
+        if (s_nf > seen_nf) {   // new encoder frames were published: one agent-scope acquire before reading enc_proj rows
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            seen_nf = s_nf;
+            __syncthreads();
+        }
+        if (anyact) {
+            // ---- L: gates of my 16 hidden units for my 16 streams; candidate (h', c') -------------------------------------
+            coop_stage(X, p.h, nb, [&](int r) { return (long long)s_sel[r] * p.bstride + (long long)(b0 + r) * RNNT_D; });
+            __syncthreads();
+            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int u = 0; u < 16; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(&X[i * COOP_LD + 16 * u + 4 * kq]);
+                const float4 w = *reinterpret_cast<const float4*>(&Wl[(16 * wave + i) * COOP_LD + 16 * u + 4 * kq]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * kq + r;                          // local stream
+                const int mm = min(m, nb - 1);
+                const int n = 64 * cg + 16 * wave + i;             // gate column (interleaved i,f,g,o)
+                float v = acc[r] + ldg1(p.egate + (long long)s_tok[mm] * (4 * RNNT_D) + n);
+                const float gf = __shfl_down(v, 1, 64), gg = __shfl_down(v, 2, 64), go = __shfl_down(v, 3, 64);
+                if ((i & 3) == 0 && m < nb) {
+                    const long long so = (long long)(b0 + m) * RNNT_D + (n >> 2);
+                    const float cin = ld_sc1f(p.c + (long long)s_sel[m] * p.bstride + so);
+                    const float c2v = sigmoidf_(gf) * cin + sigmoidf_(v) * tanhf(gg);
+                    st_sc1f(p.c + (long long)(s_sel[m] ^ 1) * p.bstride + so, c2v);
+                    st_sc1f(p.h + (long long)(s_sel[m] ^ 1) * p.bstride + so, sigmoidf_(go) * tanhf(c2v));
+                }
+            }
+        }
+        COOP_T(1)
+        if (!coop_barrier(p, bar_ctr, COOP_CG * (++bar), &s_flag)) return;
+        COOP_T(2)
+        if (anyact) {
+            // ---- J: z = tanh(enc_proj[t] + h' W_c^T + b_c), my 16 columns; K split over the 4 waves ------------------------
+            coop_stage(X, p.h, nb, [&](int r) { return (long long)(s_sel[r] ^ 1) * p.bstride + (long long)(b0 + r) * RNNT_D; });
+            __syncthreads();
+            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 4 * wave; u < 4 * wave + 4; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(&X[i * COOP_LD + 16 * u + 4 * kq]);
+                const float4 w = *reinterpret_cast<const float4*>(&Wj[i * COOP_LD + 16 * u + 4 * kq]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
+            __syncthreads();
+            {   // 256 outputs (16 streams x 16 columns), one per thread
+                const int r = tid >> 6, ln = tid & 63;
+                const float sum = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+                const int m = 4 * (ln >> 4) + r, n = 16 * cg + (ln & 15);
+                if (m < nb) {
+                    float e = 0.f;
+                    if (s_act[m]) e = ldg1(p.encp + (long long)(b0 + m) * p.fstride_f + (long long)s_fidx[m] * RNNT_D + n);
+                    st_sc1f(p.z + (long long)(b0 + m) * RNNT_D + n, tanhf(sum + ldg1(p.bjc + n) + e));
+                }
+            }
+        }
+        COOP_T(3)
+        if (!coop_barrier(p, bar_ctr, COOP_CG * (++bar), &s_flag)) return;
+        COOP_T(4)
+        if (anyact) {
+            // ---- O: logits of my 26 vocabulary rows (2 tiles x 2 K halves over the 4 waves) + argmax into the packed key ----
+            coop_stage(X, p.z, nb, [&](int r) { return (long long)(b0 + r) * RNNT_D; });
+            __syncthreads();
+            const int tile = wave >> 1, kh = wave & 1;
+            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 8 * kh; u < 8 * kh + 8; ++u) {
+                const float4 a = *reinterpret_cast<const float4*>(&X[i * COOP_LD + 16 * u + 4 * kq]);
+                const float4 w = *reinterpret_cast<const float4*>(&Wo[(16 * tile + i) * COOP_LD + 16 * u + 4 * kq]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
+            __syncthreads();
+            if (tid < 128) {   // 2 tiles x (4 regs x 64 lanes) -> thread handles (tile, r, lane)
+                const int t2 = tid >> 6, ln = tid & 63;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sum = red[(2 * t2) * 256 + r * 64 + ln] + red[(2 * t2 + 1) * 256 + r * 64 + ln];
+                    const int m = 4 * (ln >> 4) + r;
+                    const int jr = 16 * t2 + (ln & 15);            // local vocabulary row 0..31 (26 valid)
+                    const int n = 26 * cg + jr;
+                    const bool nin = jr < 26 && n < p.vocab;
+                    float v = nin ? sum + ldg1(p.bout + min(n, p.vocab - 1)) : -INFINITY;
+                    int bi = nin ? n : 0x7fffffff;
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(v, o, 16);
+                        const int oi = __shfl_xor(bi, o, 16);
+                        if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; }
+                    }
+                    if ((ln & 15) == 0 && m < nb && s_act[m] && bi != 0x7fffffff) {
+                        unsigned uu = __float_as_uint(v);
+                        uu = (uu & 0x80000000u) ? ~uu : (uu | 0x80000000u);
+                        atomicMax(p.key2 + (par ^ 1) * 64 + b0 + m, ((unsigned long long)uu << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi));
+                    }
+                }
+            }
+        }
+        if (cg == 0 && tid == 0) st_sc1i(p.ctrl + 16 + 2 * sg + (par ^ 1), ld_sc1i(p.ctrl));   // frames visible to the group's NEXT evaluation
+        if (anyact) ++evals;
+        else __builtin_amdgcn_s_sleep(64);                                                      // waiting for the encoder
+        COOP_T(5)
+        if (!coop_barrier(p, bar_ctr, COOP_CG * (++bar), &s_flag)) return;
+        COOP_T(6)
+        if (!anyact && cg == 0 && tid == 0 && (long long)__builtin_amdgcn_s_memrealtime() - t_start > 4 * p.timeout_ticks) {
+            st_sc1i(p.ctrl + 1, 3);   // the encoder never published the missing frames: abort everybody (seen in the next barrier spin)
+            st_sc1i(p.ctrl + 4, 1);
+        }
+    }
+    // ---- canonical state for the host / the next call --------------------------------------------------------------------
+    if (cg == 0 && tid < nb) {
+        const int b = b0 + tid;
+        p.tok[b] = s_tok[tid]; p.fidx[b] = s_fidx[tid]; p.nsym[b] = s_nsym[tid]; p.sel[b] = s_sel[tid]; p.count[b] = s_count[tid];
+    }
+    if (cg == 0 && tid == 0) atomicAdd(p.ctrl + 2, evals);
+    if (p.dbg && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 8; ++k) p.dbg[k] = tacc[k];
+#undef COOP_T
+}
+
+// st2[0] <- canonical (tok, fidx, nsym, sel, count); keys <- 0; nf by parity <- frames_ready
+__global__ void coop_init(int* st2, unsigned long long* key2, int* ctrl, const int* tok, const int* fidx, const int* nsym, const int* sel,
+                          const int* count, int B, int frames_ready) {
+    const int b = threadIdx.x;
+    if (b < 64) {
+        st2[0 * 64 + b] = b < B ? tok[b] : 0; st2[1 * 64 + b] = b < B ? fidx[b] : 0; st2[2 * 64 + b] = b < B ? nsym[b] : 0;
+        st2[3 * 64 + b] = b < B ? sel[b] : 0; st2[4 * 64 + b] = b < B ? count[b] : 0;
+        key2[b] = 0ull; key2[64 + b] = 0ull;
+    }
+    if (b < 32) ctrl[b] = 0;
+    __syncthreads();
+    if (b == 0) ctrl[0] = frames_ready;
+    if (b < 8) ctrl[16 + b] = frames_ready;
 }
 
 // frames_ready <- n (one thread; the kernel boundary before it released the encoder's writes)
