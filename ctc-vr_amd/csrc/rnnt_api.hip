@@ -64,6 +64,7 @@ struct rnnt_ctx {
     unsigned long long* key = nullptr;
     int* dec_ctrl = nullptr;   // persistent decoder control block: [0] frames_ready, [1] error, [2] evaluations, [3..6] cooperative decoder
     int use_persistent = 1;
+    int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
     float* coop_z = nullptr; int* coop_st2 = nullptr; unsigned long long* coop_key2 = nullptr;
     const float *wjc = nullptr, *bjc = nullptr;   // folded joint.pred_ffn o predictor.projection
@@ -206,6 +207,21 @@ void launch_gemm16(hipStream_t s, const GemmBatch& gb, int maxM, int maxN, int n
 }
 
 // wk > 0: gemm32 (32x32 tiles, large-M implicit-GEMM conv2); wk == 0: gemm16 with a shape heuristic
+// gemm_ns with the XCD-aware 1-D grid (see the kernel): ceil(ntm / 8) * 8 * ntn workgroups per descriptor
+static int prefetch_depth() {   // K blocks in flight per workgroup (register ring of gemm_ns_body): 1 or 2
+    static const int pd = getenv("RNNT_GEMM_PD") ? atoi(getenv("RNNT_GEMM_PD")) : 2;
+    return pd;
+}
+template <int MT, int NT, bool ATANH = false>
+void launch_gemm_ns(hipStream_t s, const GemmBatch& gb, int maxM, int maxN, int ng) {
+    const int ntn = (maxN + 32 * NT - 1) / (32 * NT), ntm = (maxM + 32 * MT - 1) / (32 * MT);
+    dim3 grid(((ntm + 7) / 8) * 8 * ntn, 1, ng);
+    switch (prefetch_depth()) {
+        case 1: hipLaunchKernelGGL((gemm_ns<MT, NT, 32, 1, ATANH>), grid, dim3(256), 0, s, gb, ntn, ntm); break;
+        default: hipLaunchKernelGGL((gemm_ns<MT, NT, 32, 2, ATANH>), grid, dim3(256), 0, s, gb, ntn, ntm); break;
+    }
+}
+
 int launch_gemm(rnnt_ctx* ctx, hipStream_t s, int wk, const GemmP* gs, int ng, int tag = TAG_NONE) {
     ProfScope prof(ctx, s, tag);
     GemmBatch gb;
@@ -227,13 +243,9 @@ int launch_gemm(rnnt_ctx* ctx, hipStream_t s, int wk, const GemmP* gs, int ng, i
         const int epi0 = gs[0].epi;
         if (maxM >= 1024 && K % 32 == 0 && epi0 != EPI_LSTM && epi0 != EPI_ARGMAX) {
             // large M (full-context encoder, batched subsampling, joint lattice): LDS-tiled kernel, no split-K
-            if (maxN >= 512) {
-                dim3 grid((maxN + 63) / 64, (maxM + 63) / 64, ng);
-                hipLaunchKernelGGL((gemm_ns<2, 2>), grid, dim3(256), 0, s, gb);
-            } else {
-                dim3 grid((maxN + 63) / 64, (maxM + 31) / 32, ng);
-                hipLaunchKernelGGL((gemm_ns<1, 2>), grid, dim3(256), 0, s, gb);
-            }
+            if (gs[0].a_tanh) launch_gemm_ns<2, 2, true>(s, gb, maxM, maxN, ng);
+            else if (maxN >= 512) launch_gemm_ns<2, 2>(s, gb, maxM, maxN, ng);
+            else launch_gemm_ns<1, 2>(s, gb, maxM, maxN, ng);
             LAUNCHCHK("gemm_ns");
             return RNNT_OK;
         }
@@ -386,8 +398,7 @@ int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T
         memset(&gb, 0, sizeof(gb));
         gb.g[0] = g;
         if ((rc = prepare_gemm(ctx, gb.g[0]))) return rc;
-        dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, 1);
-        hipLaunchKernelGGL((gemm_ns<2, 2>), grid, dim3(256), 0, s, gb);
+        launch_gemm_ns<2, 2>(s, gb, g.M, g.N, 1);
         LAUNCHCHK("gemm_ns");
     } else if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;
     // Linear(4864 -> 256) * sqrt(256); y2 is [VB*t', f*256 + c] (weight columns permuted to match)
@@ -409,16 +420,34 @@ int launch_gemm_tab(rnnt_ctx* ctx, hipStream_t s, const GemmP* tab_dev, int n, i
     if (ns_mode && n >= 6 && K % 32 == 0) {   // enough groups: no split-K, epilogue from registers
         // tile choice from tools/microbench2.hip (12 groups x 192 rows): the kernel is occupancy/latency-bound, so the
         // narrow shapes want many small workgroups; only K = 1024 profits from 64-deep K blocks (half the barriers)
+        // XCDs per descriptor (see gemm_ns_tab): the largest split that keeps the groups balanced
+        static const int x_env = getenv("RNNT_XCD_X") ? atoi(getenv("RNNT_XCD_X")) : 0;
+        auto pick_x = [&](int ntn) {
+            if (x_env == 1 || x_env == 2 || x_env == 4 || x_env == 8) return x_env;
+            for (int X = 2; X < 8; X *= 2)
+                if (n % (8 / X) == 0 && ntn % X == 0) return X;
+            return 8;
+        };
+        auto grid_for_tab = [&](int ntn, int ntm, int X) {
+            const int dpg = (n + 8 / X - 1) / (8 / X), cpx = (ntn + X - 1) / X;
+            return dim3(8 * dpg * cpx * ntm);
+        };
+#define NS_TAB(MT_, NT_, BK_)                                                                                              \
+    switch (prefetch_depth()) {                                                                                            \
+        case 1: hipLaunchKernelGGL((gemm_ns_tab<MT_, NT_, BK_, 1>), grid_for_tab(ntn, ntm, X), dim3(256), 0, s, tab_dev, n, ntn, ntm, X); break; \
+        default: hipLaunchKernelGGL((gemm_ns_tab<MT_, NT_, BK_, 2>), grid_for_tab(ntn, ntm, X), dim3(256), 0, s, tab_dev, n, ntn, ntm, X); break; \
+    }
         if (N >= 512) {                       // ffn1 / pointwise_conv1: 32x64 tiles
-            const int ntn = (N + 63) / 64, ntm = (maxM + 31) / 32;
-            hipLaunchKernelGGL((gemm_ns_tab<1, 2, 32>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+            const int ntn = (N + 63) / 64, ntm = (maxM + 31) / 32, X = pick_x(ntn);
+            NS_TAB(1, 2, 32)
         } else if (K >= 1024) {               // ffn2: 32x32 tiles, BK = 64
-            const int ntn = (N + 31) / 32, ntm = (maxM + 31) / 32;
-            hipLaunchKernelGGL((gemm_ns_tab<1, 1, 64>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+            const int ntn = (N + 31) / 32, ntm = (maxM + 31) / 32, X = pick_x(ntn);
+            NS_TAB(1, 1, 64)
         } else {                              // q/k/v, linear_out, pointwise_conv2: 32x32 tiles
-            const int ntn = (N + 31) / 32, ntm = (maxM + 31) / 32;
-            hipLaunchKernelGGL((gemm_ns_tab<1, 1, 32>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab_dev, n, ntn, ntm);
+            const int ntn = (N + 31) / 32, ntm = (maxM + 31) / 32, X = pick_x(ntn);
+            NS_TAB(1, 1, 32)
         }
+#undef NS_TAB
         LAUNCHCHK("gemm_ns_tab");
         return RNNT_OK;
     }
@@ -590,6 +619,27 @@ int init_decoder_ctrl(rnnt_ctx* ctx, hipStream_t s, int frames_ready) {
     LAUNCHCHK("fill_i32");
     hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, frames_ready);
     LAUNCHCHK("publish_frames");
+    return RNNT_OK;
+}
+
+// One-time check that a kernel on `s2` can stay resident while kernels on `s` run (what the pipelined resident decoder
+// relies on).  Bounded to 20 ms; on failure the pipelined path falls back to graph-launched evaluation batches.
+int probe_overlap(rnnt_ctx* ctx, hipStream_t s, hipStream_t s2) {
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->dec_ctrl, 0, 32LL);
+    LAUNCHCHK("fill_i32");
+    HIPCHK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(probe_overlap_wait, dim3(1), dim3(1), 0, s2, ctx->dec_ctrl, 2000000LL);
+    LAUNCHCHK("probe_overlap_wait");
+    hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, 1);
+    LAUNCHCHK("publish_frames");
+    HIPCHK(hipStreamSynchronize(s2));
+    HIPCHK(hipStreamSynchronize(s));
+    int r[2] = {0, 0};
+    HIPCHK(hipMemcpy(r, ctx->dec_ctrl, sizeof(r), hipMemcpyDeviceToHost));
+    ctx->overlap_ok = r[1] ? 1 : 0;
+    if (!ctx->overlap_ok)
+        fprintf(stderr, "[rnnt] kernels of two HIP streams do not overlap here (serialising profiler or shared hardware queue): "
+                        "the resident decoder is replaced by launched evaluation batches\n");
     return RNNT_OK;
 }
 
@@ -1134,6 +1184,7 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     // decode stream + events (greedy != 0): chunk c's frames are decodable once its layer-11 stage, after_norm and
     // joint.enc_ffn projection are done; the greedy steps run on ctx->dec_stream concurrently with later stages.
     hipStream_t s2 = s, caller = nullptr;
+    bool resident = false;
     if (greedy) {
         if (!ctx->dec_stream) {   // decode = the latency-critical dependent chain: highest stream priority
             int lo = 0, hi = 0;
@@ -1165,10 +1216,12 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             ctx->wf_evd.push_back(e);
         }
         ctx->pinned[8] = 0;
-        if (ctx->use_persistent && (rc = init_decoder_ctrl(ctx, s, ctx->frames_buffered))) return rc;
+        if (ctx->use_persistent && ctx->overlap_ok < 0 && (rc = probe_overlap(ctx, s, s2))) return rc;
+        resident = ctx->use_persistent && ctx->overlap_ok == 1;
+        if (resident && (rc = init_decoder_ctrl(ctx, s, ctx->frames_buffered))) return rc;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s));          // everything enqueued before this call (reset, earlier decode)
         HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[C], 0));
-        if (ctx->use_persistent && (rc = launch_persistent_decoder(ctx, s2, fb))) return rc;
+        if (resident && (rc = launch_persistent_decoder(ctx, s2, fb))) return rc;
         if (ctx->enc_stream) {                              // experiment: move the wavefront to the masked encoder stream
             HIPCHK(hipStreamWaitEvent(ctx->enc_stream, ctx->wf_ev[C], 0));
             caller = s;
@@ -1218,7 +1271,7 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
         }
         if (timing) { double t = now(); t_enc += t - tl; tl = t; }
-        if (greedy && ctx->use_persistent) {   // the resident decoder sees the chunk's frames as soon as this lands
+        if (greedy && resident) {   // the resident decoder sees the chunk's frames as soon as this lands
             hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, ci[c].fpos + ci[c].tq);
             LAUNCHCHK("publish_frames");
         } else if (greedy) {
@@ -1253,7 +1306,7 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     if (timing) fprintf(stderr, "[rnnt timing] host enqueue: encoder stages %.2f ms, decode batches %.2f ms\n", t_enc, t_dec);
     if (frames_out) *frames_out = fb - fb0;
     ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
-    if (greedy && ctx->use_persistent) {
+    if (greedy && resident) {
         double t_e = 0;
         if (timing) { (void)hipStreamSynchronize(s); t_e = now(); }
         if ((rc = finish_persistent_decoder(ctx, s2))) return rc;      // synchronises the decode stream (=> encoder done too)
@@ -1442,8 +1495,7 @@ int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32
         g.a_n1 = T * U; g.a_n2 = U; g.a_s0 = (long long)U * D; g.a_s1 = 0; g.a_s2 = D;   // A row = pp[b, u]
         g.a_tanh = 1; g.X = e; g.x_n = U; g.x_s0 = D;                                    // X row = e[(b,t)] = e[m / U]
         if ((rc = prepare_gemm(ctx, g))) return rc;
-        dim3 grid((V + 63) / 64, (g.M + 63) / 64, 1);
-        hipLaunchKernelGGL((gemm_ns<2, 2>), grid, dim3(256), 0, s, gb);
+        launch_gemm_ns<2, 2, true>(s, gb, g.M, V, 1);
         LAUNCHCHK("gemm_ns(joint lattice)");
     }
     if (mode == 1) {

@@ -633,7 +633,13 @@ __global__ __launch_bounds__(64 * WK) void gemm16_tab(const GemmP* __restrict__ 
 // LDS rows are padded to 36 floats: the 16 rows of a ds_read_b128 fragment read start on 16 distinct 4-bank groups.
 // The LayerNorm prologue is applied while the A tile is written to LDS.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int NS_BK = 32>
+#ifdef NS_TRACE   // tools/microbench3.hip only: per-workgroup phase time stamps (100 MHz) of gemm_ns_body
+__device__ long long ns_trace[8192 * 8];
+#define NS_STAMP(k_) { if (threadIdx.x == 0 && blockIdx.x < 8192) ns_trace[blockIdx.x * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#else
+#define NS_STAMP(k_)
+#endif
+template <int MT, int NT, int NS_BK = 32, int PD = 1, bool ATANH = false>
 __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int NS_LD = NS_BK + 4;       // row stride in floats: 16 fragment rows start on 16 distinct 4-bank groups
@@ -644,40 +650,13 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * NS_LD];
     __shared__ __attribute__((aligned(16))) float Ws[2][BN * NS_LD];
     __shared__ float st[2 * BM];
+    __shared__ __attribute__((aligned(16))) float lngb[2 * RNNT_D];   // LayerNorm gamma | beta (K = 256 when the prologue is on)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm0 = by * BM, bn0 = bx * BN;
     if (bm0 >= p.M || bn0 >= p.N) return;   // whole workgroup out of range (uniform)
     const int i = lane & 15, kq = lane >> 4;
     const bool ln = p.ln_g != nullptr;
-    if (ln) {
-        const int grp = tid >> 4, l16 = tid & 15;
-        for (int r = grp; r < BM; r += 16) {
-            const float* rp = p.A + a_row_off(p, min(bm0 + r, p.M - 1));
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ldg4(rp + 4 * (l16 + 16 * j));
-            float sm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
-            const float mu = sm * (1.0f / 256.0f);
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dx = v[j].x - mu, dy = v[j].y - mu, dz = v[j].z - mu, dw = v[j].w - mu;
-                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 16);
-            if (l16 == 0) {
-                st[r * 2] = mu;
-                st[r * 2 + 1] = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
-            }
-        }
-        __syncthreads();
-    }
-
+    NS_STAMP(0)
     // staging assignment: thread covers tile rows srow + RPP*j, columns c4..c4+3 of the current K block
     const int c4 = (tid % LPR) * 4;
     const int srow = tid / LPR;
@@ -685,19 +664,16 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     const float* xg[AJ];
     const float* wg[WJ];
     float amean[AJ], arstd[AJ];
-    const bool atanh_ = p.a_tanh != 0;
+    constexpr bool atanh_ = ATANH;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int am = min(bm0 + srow + RPP * j, p.M - 1);
         ag[j] = p.A + a_row_off(p, am);
         xg[j] = atanh_ ? p.X + (long long)fastdiv(am, p.x_n, p.x_n_magic, p.x_n_shift) * p.x_s0 : p.A;
         if (p.Asel) ag[j] += (long long)(ldgi(p.Asel + am) ^ p.asel_invert) * p.asel_stride;
-        amean[j] = ln ? st[(srow + RPP * j) * 2] : 0.f;
-        arstd[j] = ln ? st[(srow + RPP * j) * 2 + 1] : 1.f;
     }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) wg[j] = p.W + (long long)min(bn0 + srow + RPP * j, p.N - 1) * p.ldw;
-
     f32x4_ acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -707,31 +683,33 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     const int wm = (wave >> 1) * (16 * MT), wn = (wave & 1) * (16 * NT);   // this wave's sub-tile inside the workgroup tile
     const int nb = p.K / NS_BK;
     const bool aplain = p.a_plain != 0;
-    float4 ra[AJ], rx[AJ], rw[WJ], rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // PD K blocks are in flight in registers (slot = block % PD): a workgroup of this size keeps only ~12 KB per block
+    // in flight, and with ~2 us to the Infinity Cache the K loop is bound by bytes in flight, not by the MFMA pipe.
+    float4 ra[PD][AJ], rx[PD][ATANH ? AJ : 1], rw[PD][WJ];
 
-#define NS_GLOAD(blk_)                                                                                         \
+#define NS_GLOAD(blk_, sl_)                                                                                    \
     {                                                                                                          \
         const int kk_ = (blk_) * NS_BK + c4;                                                                   \
         const long long ko_ = aplain ? (long long)kk_ : a_k_off(p, kk_);                                       \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = ldg4(ag[j] + ko_);                              \
-        if (atanh_) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) rx[j] = ldg4(xg[j] + kk_); }              \
-        _Pragma("unroll") for (int j = 0; j < WJ; ++j) rw[j] = ldg4(wg[j] + kk_);                              \
-        if (ln) {                                                                                              \
-            rg = ldg4(p.ln_g + kk_);                                                                           \
-            rb = ldg4(p.ln_b + kk_);                                                                           \
-        }                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[sl_][j] = ldg4(ag[j] + ko_);                         \
+        if (atanh_) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) rx[sl_][ATANH ? j : 0] = ldg4(xg[j] + kk_); } \
+        _Pragma("unroll") for (int j = 0; j < WJ; ++j) rw[sl_][j] = ldg4(wg[j] + kk_);                         \
     }
-#define NS_LSTORE(buf_)                                                                                        \
+#define NS_LSTORE(buf_, sl_, blk_)                                                                             \
     {                                                                                                          \
+        float4 rg = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);                     \
+        if (ln) {                                                                                              \
+            rg = *reinterpret_cast<const float4*>(&lngb[(blk_) * NS_BK + c4]);                                 \
+            rb = *reinterpret_cast<const float4*>(&lngb[RNNT_D + (blk_) * NS_BK + c4]);                       \
+        }                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                       \
-            float4 v_ = ra[j];                                                                                 \
+            float4 v_ = ra[sl_][j];                                                                            \
             if (atanh_) {                                                                                      \
-                v_.x = tanhf(v_.x + rx[j].x);                                                                  \
-                v_.y = tanhf(v_.y + rx[j].y);                                                                  \
-                v_.z = tanhf(v_.z + rx[j].z);                                                                  \
-                v_.w = tanhf(v_.w + rx[j].w);                                                                  \
+                const float4 x_ = rx[sl_][ATANH ? j : 0];                                                      \
+                v_.x = tanhf(v_.x + x_.x);                                                                     \
+                v_.y = tanhf(v_.y + x_.y);                                                                     \
+                v_.z = tanhf(v_.z + x_.z);                                                                     \
+                v_.w = tanhf(v_.w + x_.w);                                                                     \
             }                                                                                                  \
             if (ln) {                                                                                          \
                 v_.x = (v_.x - amean[j]) * arstd[j] * rg.x + rb.x;                                             \
@@ -742,44 +720,98 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
             *reinterpret_cast<float4*>(&As[buf_][(srow + RPP * j) * NS_LD + c4]) = v_;                         \
         }                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < WJ; ++j)                                                         \
-            *reinterpret_cast<float4*>(&Ws[buf_][(srow + RPP * j) * NS_LD + c4]) = rw[j];                      \
+            *reinterpret_cast<float4*>(&Ws[buf_][(srow + RPP * j) * NS_LD + c4]) = rw[sl_][j];                 \
     }
 
-    NS_GLOAD(0)
-    NS_LSTORE(0)
-    __syncthreads();
-    for (int blk = 0; blk < nb; ++blk) {
-        const int buf = blk & 1;
-        if (blk + 1 < nb) NS_GLOAD(blk + 1)
 #pragma unroll
-        for (int u = 0; u < NS_BK / 16; ++u) {
-            float4 a[MT], w[NT];
+    for (int d = 0; d < PD; ++d)
+        if (d < nb) NS_GLOAD(d, d)
+    // the LayerNorm statistics are only needed when a block is written to LDS: their loads travel with the first blocks'
+    if (ln) {
+        lngb[tid] = ldg1(p.ln_g + tid);
+        lngb[RNNT_D + tid] = ldg1(p.ln_b + tid);
+        // statistics of the BM rows: 16 lanes per row, all rows of a lane group loaded before the first reduction (one
+        // memory round trip instead of BM/16)
+        const int grp = tid >> 4, l16 = tid & 15;
+        constexpr int RG = BM / 16;
+        float4 v[RG][4];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(&As[buf][(wm + 16 * mt + i) * NS_LD + 16 * u + 4 * kq]);
+        for (int q = 0; q < RG; ++q) {
+            const float* rp = p.A + a_row_off(p, min(bm0 + grp + 16 * q, p.M - 1));
 #pragma unroll
-            for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const float4*>(&Ws[buf][(wn + 16 * t + i) * NS_LD + 16 * u + 4 * kq]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, w[t].x, acc[mt][t], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, w[t].y, acc[mt][t], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, w[t].z, acc[mt][t], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, w[t].w, acc[mt][t], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) v[q][j] = ldg4(rp + 4 * (l16 + 16 * j));
         }
-        if (blk + 1 < nb) NS_LSTORE(buf ^ 1)
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += (v[q][j].x + v[q][j].y) + (v[q][j].z + v[q][j].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+            const float mu = sm * (1.0f / 256.0f);
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = v[q][j].x - mu, dy = v[q][j].y - mu, dz = v[q][j].z - mu, dw = v[q][j].w - mu;
+                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
+            if (l16 == 0) {
+                st[(grp + 16 * q) * 2] = mu;
+                st[(grp + 16 * q) * 2 + 1] = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
+            }
+        }
         __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        amean[j] = ln ? st[(srow + RPP * j) * 2] : 0.f;
+        arstd[j] = ln ? st[(srow + RPP * j) * 2 + 1] : 1.f;
+    }
+    NS_STAMP(1)
+    NS_LSTORE(0, 0, 0)
+    __syncthreads();
+    NS_STAMP(2)
+    for (int blk0 = 0; blk0 < nb; blk0 += PD) {
+#pragma unroll
+        for (int jj = 0; jj < PD; ++jj) {
+            const int blk = blk0 + jj;
+            if (blk < nb) {   // uniform
+                const int buf = blk & 1;
+                if (blk + PD < nb) NS_GLOAD(blk + PD, jj)   // slot jj was written to LDS one block ago
+#pragma unroll
+                for (int u = 0; u < NS_BK / 16; ++u) {
+                    float4 a[MT], w[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(&As[buf][(wm + 16 * mt + i) * NS_LD + 16 * u + 4 * kq]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const float4*>(&Ws[buf][(wn + 16 * t + i) * NS_LD + 16 * u + 4 * kq]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, w[t].x, acc[mt][t], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, w[t].y, acc[mt][t], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, w[t].z, acc[mt][t], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, w[t].w, acc[mt][t], 0, 0, 0);
+                }
+                if (blk + 1 < nb) NS_LSTORE(buf ^ 1, (jj + 1) % PD, blk + 1)
+                __syncthreads();
+            }
+        }
     }
 #undef NS_GLOAD
 #undef NS_LSTORE
+    NS_STAMP(3)
     const int m0 = bm0 + wm, n0 = bn0 + wn;
     if (m0 >= p.M || n0 >= p.N) return;     // this wave's sub-tile is out of range (all barriers are behind us)
 
@@ -817,28 +849,42 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
             }
         }
     }
+    NS_STAMP(4)
 }
 
 // single-descriptor launch of the LDS-tiled GEMM (conv2 implicit GEMM at M ~ 36 k rows): 2-D grid, descriptor in kernarg
-template <int MT, int NT, int BK = 32>
-__global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb) {
-    gemm_ns_body<MT, NT, BK>(gb.g[blockIdx.z], blockIdx.x, blockIdx.y);
+template <int MT, int NT, int BK = 32, int PD = 2, bool ATANH = false>
+__global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb, int ntn, int ntm) {
+    // 1-D grid per descriptor, dealt round-robin over the 8 XCDs: XCD x runs M-tiles x, x+8, ... and, back to back, all
+    // column tiles of each, so an A row block (for conv2: 590 KB of implicit-GEMM input) is fetched into ONE L2 instead
+    // of into the L2 of every XCD a column tile landed on.  Placement is a speed hint only.
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int mt = (slot / ntn) * 8 + xcd;
+    if (mt >= ntm) return;
+    gemm_ns_body<MT, NT, BK, PD, ATANH>(gb.g[blockIdx.z], slot % ntn, mt);
 }
 
 // XCD-aware work mapping (guide T1): workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
 // private 4 MiB L2.  A wavefront stage multiplies 12 different weight matrices at once (12+ MB): dealt naively,
-// every XCD touches all of them and the operands stream from the Infinity Cache.  Here each (descriptor,
-// column-tile) pair -- i.e. one 64-row slice of one weight matrix -- is pinned to ONE XCD and its M-tiles run
-// there back to back, so a slice is fetched once per launch.  Placement is a speed hint only.
-template <int MT, int NT, int BK = 32>
-__global__ __launch_bounds__(256) void gemm_ns_tab(const GemmP* __restrict__ tab, int n_desc, int ntn, int ntm) {
+// every XCD touches all of them and the operands stream from the Infinity Cache.  Here the 8 XCDs are split into
+// 8/X groups of X XCDs; descriptor g belongs to group g % (8/X), and inside the group column tile n runs on XCD
+// n % X, its M-tiles back to back.  So a weight slice is fetched into ONE L2 and an activation block into X of them
+// (X = 8: every XCD takes one column tile of every descriptor; X = 2: a descriptor lives on two XCDs).
+// Placement is a speed hint only.
+template <int MT, int NT, int BK = 32, int PD = 2>
+__global__ __launch_bounds__(256) void gemm_ns_tab(const GemmP* __restrict__ tab, int n_desc, int ntn, int ntm, int X) {
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int pair = (slot / ntm) * 8 + xcd;
-    if (pair >= n_desc * ntn) return;
-    const int g = pair / ntn;
+    const int G8 = 8 / X, grp = xcd / X, xin = xcd - grp * X;
+    const int cpx = (ntn + X - 1) / X;           // column tiles per XCD and descriptor
+    const int per = cpx * ntm;
+    const int gi = slot / per, rem = slot - gi * per;
+    const int ni = rem / ntm, m = rem - ni * ntm;
+    const int g = gi * G8 + grp, n = ni * X + xin;
+    if (g >= n_desc || n >= ntn) return;
     const GemmP p = tab[g];   // by-value copy: the fields live in SGPRs instead of being re-read inside the K loop
-    gemm_ns_body<MT, NT, BK>(p, pair - g * ntn, slot % ntm);
+    gemm_ns_body<MT, NT, BK, PD, false>(p, n, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1231,7 +1277,7 @@ struct DecP {
     long long timeout_ticks;   // s_memrealtime ticks (100 MHz)
 };
 
-template <int SPW, int NTH, typename Epi>
+template <int SPW, int NTH, int U = 2, typename Epi>
 __device__ __forceinline__ void dec_matvec(const float* __restrict__ W, int nrows, const float (*x)[RNNT_D], Epi epi) {
     const int tid = threadIdx.x, g = tid >> 4, l = tid & 15;
     float4 xv[SPW][4];
@@ -1239,7 +1285,7 @@ __device__ __forceinline__ void dec_matvec(const float* __restrict__ W, int nrow
     for (int s = 0; s < SPW; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) xv[s][j] = *reinterpret_cast<const float4*>(&x[s][4 * l + 64 * j]);
-    constexpr int U = 2;            // weight rows in flight per lane group (x NTH/16 groups: 128 KB per CU at 1024 threads)
+    // U weight rows in flight per lane group: U x NTH/16 KB per CU
     constexpr int RP = NTH / 16;    // rows per pass of the workgroup
     for (int r0 = 0; r0 < nrows; r0 += RP * U) {
         float4 w[U][4];
@@ -1446,7 +1492,7 @@ __global__ __launch_bounds__(NTH) void greedy_persistent(DecP p) {
 // The results are those of the sequential loop (same operands and summation order per logit).  The dependent chain is
 // (#symbols) x (L + Jc + O) + (#blank runs / KF) x O instead of (#symbols + #frames) x (L + Jc + O).
 // ------------------------------------------------------------------------------------------------
-template <int KF>
+template <int KF, int UL = 2, int UO = 2>
 __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
     constexpr int NTH = 512;
     __shared__ __attribute__((aligned(16))) float hs[1][RNNT_D], cs[RNNT_D], h2[1][RNNT_D], c2[RNNT_D], pp[RNNT_D];
@@ -1496,7 +1542,7 @@ __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
         const int kf = dirty ? 1 : min(KF, min(s_ctl[1], p.n_total) - fidx);
         if (dirty) {
             // ---- predictor step: gates = E[tok] + W_hh h; candidate (h', c'); pp = W_c h' + b_c ---------------------------
-            dec_matvec<1, NTH>(p.whh, 4 * RNNT_D, hs, [&](int n, const float* acc) {
+            dec_matvec<1, NTH, UL>(p.whh, 4 * RNNT_D, hs, [&](int n, const float* acc) {
                 gates[n] = acc[0] + ldg1(p.egate + (long long)tok * (4 * RNNT_D) + n);
             });
             __syncthreads();
@@ -1507,7 +1553,7 @@ __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
                 h2[0][tid] = sigmoidf_(gt.w) * tanhf(cc);
             }
             __syncthreads();
-            dec_matvec<1, NTH>(p.wjc, RNNT_D, h2, [&](int n, const float* acc) { pp[n] = acc[0] + ldg1(p.bjc + n); });
+            dec_matvec<1, NTH, UL>(p.wjc, RNNT_D, h2, [&](int n, const float* acc) { pp[n] = acc[0] + ldg1(p.bjc + n); });
             dirty = false;
             __syncthreads();
         }
@@ -1523,12 +1569,12 @@ __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
 #pragma unroll
         for (int k = 0; k < KF; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
         if (KF > 1 && kf == 1) {
-            dec_matvec<1, NTH>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
+            dec_matvec<1, NTH, UL>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
                 const float v = acc[0] + ldg1(p.bout + n);
                 if (v > bv[0]) { bv[0] = v; bi[0] = n; }
             });
         } else {
-            dec_matvec<KF, NTH>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
+            dec_matvec<KF, NTH, UO>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
                 const float bo = ldg1(p.bout + n);
 #pragma unroll
                 for (int k = 0; k < KF; ++k) {
@@ -1900,6 +1946,19 @@ __global__ void coop_init(int* st2, unsigned long long* key2, int* ctrl, const i
 // frames_ready <- n (one thread; the kernel boundary before it released the encoder's writes)
 __global__ void publish_frames(int* ctrl, int n) {
     __hip_atomic_store(ctrl, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Do kernels of two streams really run at the same time?  ctrl[1] <- 1 if ctrl[0] becomes non-zero within `ticks`
+// (100 MHz) while this kernel is resident.  A profiler that serialises dispatches, or two streams folded onto one
+// hardware queue, make it time out; the resident decoder is then not used.
+__global__ void probe_overlap_wait(int* ctrl, long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    int seen = 0;
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        if (__hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    ctrl[1] = seen;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ template <int WK, int MT, int NT> void launch_tab(hipStream_t s, const GemmP* ta
 }
 template <int MT, int NT, int BK = 32> void launch_ns(hipStream_t s, const GemmP* tab, int n, int M, int N) {
     const int ntn = (N + 32 * NT - 1) / (32 * NT), ntm = (M + 32 * MT - 1) / (32 * MT);
-    hipLaunchKernelGGL((gemm_ns_tab<MT, NT, BK>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab, n, ntn, ntm);
+    hipLaunchKernelGGL((gemm_ns_tab<MT, NT, BK, 1>), dim3((n * ntn + 7) / 8 * 8 * ntm), dim3(256), 0, s, tab, n, ntn, ntm, 8);
 }
 static double time_eager(hipStream_t s, int iters, const std::function<void(hipStream_t)>& f) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
