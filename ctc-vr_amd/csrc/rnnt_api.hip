@@ -334,8 +334,22 @@ int build_layer(rnnt_ctx* ctx, int l, int B, int tq, int T2, int kv_row0, int po
     return RNNT_OK;
 }
 
+// streaming chunks (<= 4 new frames): direct-stream kernel; dynamic LDS = 4 score rows + the PV partial sums
+static bool attn_stream_ok(int tq, int T2) {
+    static const int on = getenv("RNNT_ATTN_STREAM") ? atoi(getenv("RNNT_ATTN_STREAM")) : 1;
+    return on && tq <= 4 && T2 >= 1 && T2 <= 4096;
+}
+static int attn_t2cap(int T2) { return (T2 + 63) / 64 * 64; }
+static size_t attn_stream_lds(int t2cap) { return (size_t)(4 * t2cap + 16 * 4 * RNNT_DK) * sizeof(float); }
+
 int launch_attn(rnnt_ctx* ctx, hipStream_t s, const AttnP& a, int B) {
     ProfScope prof(ctx, s, TAG_ATTN);
+    if (attn_stream_ok(a.tq, a.T2)) {
+        const int cap = attn_t2cap(a.T2);
+        hipLaunchKernelGGL(rel_attention_stream, dim3(B * RNNT_H), dim3(256), attn_stream_lds(cap), s, a, cap);
+        LAUNCHCHK("rel_attention_stream");
+        return RNNT_OK;
+    }
     const int nq = a.tq <= 4 ? 1 : (a.tq <= 8 ? 2 : 4);
     dim3 grid(B * RNNT_H, (a.tq + 4 * nq - 1) / (4 * nq));
     if (nq == 1) hipLaunchKernelGGL(rel_attention<1>, grid, dim3(256), 0, s, a);
@@ -1127,14 +1141,14 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         c0 = c1;
     }
     // ---- (b) wavefront tables ---------------------------------------------------------------------------------
-    struct Launch { int type, off, n, maxM; };   // type 0..9 gemm (ffn1m ffn2m qkv out pw1 pw2 ffn1 ffn2), 10 attn, 11 dw, 12 ln
+    struct Launch { int type, off, n, maxM, maxT2; };   // type 0..9 gemm (ffn1m ffn2m qkv out pw1 pw2 ffn1 ffn2), 10 attn, 11 dw, 12 ln
     std::vector<GemmP> gt; std::vector<AttnP> at; std::vector<DwP> dt; std::vector<LnP> lt;
     std::vector<Launch> seq;
     gt.reserve((size_t)C * L * 12); at.reserve((size_t)C * L); dt.reserve((size_t)C * L); lt.reserve((size_t)C * (L + 1));
     std::vector<LayerDescs> cur;
     for (int st = 0; st < C + L - 1; ++st) {
         cur.clear();
-        int maxM = 0, maxtq = 0;
+        int maxM = 0, maxtq = 0, maxT2 = 0;
         for (int l = 0; l < L; ++l) {
             const int c = st - l;
             if (c < 0 || c >= C) continue;
@@ -1145,28 +1159,29 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             cur.push_back(d);
             if (B * ci[c].tq > maxM) maxM = B * ci[c].tq;
             if (ci[c].tq > maxtq) maxtq = ci[c].tq;
+            if (ci[c].T2 > maxT2) maxT2 = ci[c].T2;
         }
         const int n = (int)cur.size();
         auto add_g = [&](int type, GemmP LayerDescs::*f) -> int {
-            seq.push_back({type, (int)gt.size(), n, maxM});
+            seq.push_back({type, (int)gt.size(), n, maxM, 0});
             for (auto& d : cur) { GemmP g = d.*f; int r2 = prepare_gemm(ctx, g); if (r2) return r2; gt.push_back(g); }
             return 0;
         };
         if ((rc = add_g(0, &LayerDescs::ffn1m))) return rc;
         if ((rc = add_g(1, &LayerDescs::ffn2m))) return rc;
-        seq.push_back({2, (int)gt.size(), 3 * n, maxM});
+        seq.push_back({2, (int)gt.size(), 3 * n, maxM, 0});
         for (auto& d : cur)
             for (int i = 0; i < 3; ++i) { GemmP g = d.qkv[i]; if ((rc = prepare_gemm(ctx, g))) return rc; gt.push_back(g); }
-        seq.push_back({10, (int)at.size(), n, maxtq});
+        seq.push_back({10, (int)at.size(), n, maxtq, maxT2});
         for (auto& d : cur) at.push_back(d.attn);
         if ((rc = add_g(3, &LayerDescs::out))) return rc;
         if ((rc = add_g(4, &LayerDescs::pw1))) return rc;
-        seq.push_back({11, (int)dt.size(), n, maxM});
+        seq.push_back({11, (int)dt.size(), n, maxM, 0});
         for (auto& d : cur) dt.push_back(d.dw);
         if ((rc = add_g(5, &LayerDescs::pw2))) return rc;
         if ((rc = add_g(6, &LayerDescs::ffn1))) return rc;
         if ((rc = add_g(7, &LayerDescs::ffn2))) return rc;
-        seq.push_back({12, (int)lt.size(), n, maxM});
+        seq.push_back({12, (int)lt.size(), n, maxM, 0});
         for (auto& d : cur) lt.push_back(d.lnf);
     }
     if ((rc = grow(ctx, &ctx->wf_gtab, &ctx->wf_gcap, gt.size()))) return rc;
@@ -1243,6 +1258,12 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
                 if ((rc = launch_gemm_tab(ctx, s, ctx->wf_gtab + q.off, q.n, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
             } else if (q.type == 10) {
                 ProfScope prof(ctx, s, TAG_ATTN);
+                if (attn_stream_ok(q.maxM, q.maxT2 > 0 ? q.maxT2 : 1)) {
+                    const int cap = attn_t2cap(q.maxT2);
+                    hipLaunchKernelGGL(rel_attention_stream_tab, dim3(B * RNNT_H, 1, q.n), dim3(256), attn_stream_lds(cap), s, ctx->wf_atab + q.off, cap);
+                    LAUNCHCHK("rel_attention_stream_tab");
+                    continue;
+                }
                 const int nq = q.maxM <= 4 ? 1 : (q.maxM <= 8 ? 2 : 4);
                 dim3 grid(B * RNNT_H, (q.maxM + 4 * nq - 1) / (4 * nq), q.n);
                 if (nq == 1) hipLaunchKernelGGL(rel_attention_tab<1>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);

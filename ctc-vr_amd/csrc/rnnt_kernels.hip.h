@@ -105,12 +105,18 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     const f32x4g v = *(const RNNT_GAS f32x4g*)p;
     return make_float4(v[0], v[1], v[2], v[3]);
 }
+// read-once streams (K/V cache rows): non-temporal, so that they do not evict the weights other kernels keep in L2
+__device__ __forceinline__ float4 ldg4_nt(const float* p) {
+    const f32x4g v = __builtin_nontemporal_load((const RNNT_GAS f32x4g*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float ldg1(const float* p) { return *(const RNNT_GAS float*)p; }
 __device__ __forceinline__ int ldgi(const int* p) { return *(const RNNT_GAS int*)p; }
 __device__ __forceinline__ void stg1(float* p, float v) { *(RNNT_GAS float*)p = v; }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *(RNNT_GAS f32x4g*)p = (f32x4g){v.x, v.y, v.z, v.w}; }
 #else   // host pass of the single-source compile: never executed
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldg4_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float ldg1(const float* p) { return *p; }
 __device__ __forceinline__ int ldgi(const int* p) { return *p; }
 __device__ __forceinline__ void stg1(float* p, float v) { *p = v; }
@@ -1104,6 +1110,140 @@ template <int NQ>
 __global__ __launch_bounds__(256) void rel_attention_tab(const AttnP* __restrict__ tab) {
     const AttnP p = tab[blockIdx.z];
     rel_attention_body<NQ>(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rel_attention_stream: the same attention for a STREAMING chunk (tq <= 4 new frames against a long cache).  With so
+// few queries there is nothing to reuse a staged K tile for, and the kernel is a pure stream over the cache
+// (K, V: 512 B per key and head from HBM / Infinity Cache; the positional rows come from L2).  So nothing is staged:
+//   scores   16 lanes per key read the key's 64-float K row and P row as one float4 each (256 contiguous bytes per
+//            row and instruction), multiply against the 4 queries' (q+u), (q+v) slices held in registers, and reduce
+//            over the 16 lanes; 4 keys per lane group are in flight per iteration (8 independent 16-B loads per lane);
+//   softmax  wave w owns query w: max / exp / sum over the score row in LDS;
+//   PV       16 lanes per key again (float4 of V per lane), per-group partial sums, one LDS reduction over 16 groups.
+// One workgroup per (stream, head); LDS = 4 score rows + 16 KB of partial sums, so 8 workgroups fit a CU and their
+// phases interleave.  Dynamic LDS: (4 * t2cap + 16 * 4 * 64) floats.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rel_attention_stream_body(const AttnP& P, float* smem, int t2cap) {
+    const float* __restrict__ kc = P.kc;
+    const float* __restrict__ vc = P.vc;
+    const int tq = P.tq, T2 = P.T2;
+    float* S = smem;                       // [4][t2cap] scores, then probabilities
+    float* red = smem + 4 * t2cap;         // [16 groups][4 queries][64]
+    __shared__ float linv[4];
+    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = tid >> 4, l16 = tid & 15;
+    const int nk = P.klen ? min(ldgi(P.klen + b), T2) : T2;
+    const float* kbase = kc + ((long long)b * P.kv_stride + P.kv_start) * RNNT_D + h * RNNT_DK + 4 * l16;
+    const float* vbase = vc + ((long long)b * P.kv_stride + P.kv_start) * RNNT_D + h * RNNT_DK + 4 * l16;
+    const float* pbase = P.ptab + (long long)P.pos_start * RNNT_D + h * RNNT_DK + 4 * l16;
+    // The first K/P rows travel together with the query rows.  Register double buffering of K/P/V and V rows fetched
+    // across the softmax were measured slower: they cost the fifth wave per SIMD (> 96 VGPRs).
+    float4 ka[4], pa[4];
+#define ATS_LOAD(kk_, pp_, j0_)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+        const int j_ = min((j0_) + g + 16 * u, nk - 1);                                               \
+        kk_[u] = ldg4_nt(kbase + (long long)j_ * RNNT_D);                                             \
+        pp_[u] = ldg4(pbase + (long long)j_ * RNNT_D);                                                \
+    }
+#define ATS_SCORE(kk_, pp_, j0_)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+        const int j_ = (j0_) + g + 16 * u;                                                            \
+        _Pragma("unroll") for (int iq = 0; iq < 4; ++iq) {                                            \
+            float t = 0.f;                                                                            \
+            t = fmaf(qu[iq].x, kk_[u].x, t);                                                          \
+            t = fmaf(qu[iq].y, kk_[u].y, t);                                                          \
+            t = fmaf(qu[iq].z, kk_[u].z, t);                                                          \
+            t = fmaf(qu[iq].w, kk_[u].w, t);                                                          \
+            t = fmaf(qv[iq].x, pp_[u].x, t);                                                          \
+            t = fmaf(qv[iq].y, pp_[u].y, t);                                                          \
+            t = fmaf(qv[iq].z, pp_[u].z, t);                                                          \
+            t = fmaf(qv[iq].w, pp_[u].w, t);                                                          \
+            _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 16);              \
+            if (l16 == iq && j_ < nk) S[iq * t2cap + j_] = t * 0.125f;                                \
+        }                                                                                             \
+    }
+    ATS_LOAD(ka, pa, 0)
+    // this lane's 4-float slice of every query, with the two biases
+    float4 qu[4], qv[4];
+    {
+        const float4 bu = ldg4(P.bias_u + h * RNNT_DK + 4 * l16), bv = ldg4(P.bias_v + h * RNNT_DK + 4 * l16);
+#pragma unroll
+        for (int iq = 0; iq < 4; ++iq) {
+            float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iq < tq) qq = ldg4(P.q + ((long long)b * tq + iq) * RNNT_D + h * RNNT_DK + 4 * l16);
+            qu[iq] = make_float4(qq.x + bu.x, qq.y + bu.y, qq.z + bu.z, qq.w + bu.w);
+            qv[iq] = make_float4(qq.x + bv.x, qq.y + bv.y, qq.z + bv.z, qq.w + bv.w);
+        }
+    }
+    // ---- scores --------------------------------------------------------------------------------------------------------
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+        if (j0 > 0) ATS_LOAD(ka, pa, j0)
+        ATS_SCORE(ka, pa, j0)
+    }
+#undef ATS_LOAD
+#undef ATS_SCORE
+    __syncthreads();
+    // ---- softmax: wave w = query w ---------------------------------------------------------------------------------------
+    {
+        float* row = S + wave * t2cap;
+        float m = -INFINITY;
+        for (int j = lane; j < nk; j += 64) m = fmaxf(m, row[j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < nk; j += 64) {
+            const float e = expf(row[j] - m);
+            row[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) linv[wave] = 1.0f / sum;
+    }
+    __syncthreads();
+    // ---- PV: group g takes keys g, g+16, ... -------------------------------------------------------------------------------
+    float4 acc[4];
+#pragma unroll
+    for (int iq = 0; iq < 4; ++iq) acc[iq] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define ATS_PV(vv_, j0_)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+        const int j_ = (j0_) + g + 16 * u;                                                            \
+        if (j_ < nk) {                                                                                \
+            _Pragma("unroll") for (int iq = 0; iq < 4; ++iq) {                                        \
+                const float pj = S[iq * t2cap + j_];                                                  \
+                acc[iq].x = fmaf(pj, vv_[u].x, acc[iq].x);                                            \
+                acc[iq].y = fmaf(pj, vv_[u].y, acc[iq].y);                                            \
+                acc[iq].z = fmaf(pj, vv_[u].z, acc[iq].z);                                            \
+                acc[iq].w = fmaf(pj, vv_[u].w, acc[iq].w);                                            \
+            }                                                                                         \
+        }                                                                                             \
+    }
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+        float4 va[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) va[u] = ldg4_nt(vbase + (long long)min(j0 + g + 16 * u, nk - 1) * RNNT_D);
+        ATS_PV(va, j0)
+    }
+#undef ATS_PV
+#pragma unroll
+    for (int iq = 0; iq < 4; ++iq) *reinterpret_cast<float4*>(&red[(g * 4 + iq) * RNNT_DK + 4 * l16]) = acc[iq];
+    __syncthreads();
+    {   // thread = (query, d): sum the 16 groups in a fixed order
+        const int iq = tid >> 6, d = tid & 63;
+        float o = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) o += red[(gg * 4 + iq) * RNNT_DK + d];
+        if (iq < tq) stg1(P.out + ((long long)b * tq + iq) * RNNT_D + h * RNNT_DK + d, o * linv[iq]);
+    }
+}
+__global__ __launch_bounds__(256) void rel_attention_stream(AttnP p, int t2cap) {
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    rel_attention_stream_body(p, att_smem, t2cap);
+}
+__global__ __launch_bounds__(256) void rel_attention_stream_tab(const AttnP* __restrict__ tab, int t2cap) {
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    const AttnP p = tab[blockIdx.z];
+    rel_attention_stream_body(p, att_smem, t2cap);
 }
 
 // ------------------------------------------------------------------------------------------------
