@@ -39,6 +39,30 @@ def sub_len(t):
     return ((t - 3) // 2 + 1 - 3) // 2 + 1
 
 
+# kernel behind each launch site (ctc-vr_amd/csrc/rnnt_kernels.hip.h) and the prefix rocprofv3 prints for it
+SITE_KERNEL = {"conv2": "gemm_ns<2,2,32> (conv2 implicit GEMM)", "ffn1": "gemm_ns_tab<1,2,32> (ffn w_1)", "ffn2": "gemm_ns_tab<1,1,64> (ffn w_2)",
+               "qkv": "gemm_ns_tab<1,1,32> (linear_q/k/v)", "attn_out": "gemm_ns_tab<1,1,32> (linear_out)", "pw1": "gemm_ns_tab<1,2,32> (pointwise_conv1)",
+               "pw2": "gemm_ns_tab<1,1,32> (pointwise_conv2)", "attn": "rel_attention_stream_tab", "dwconv": "dwconv_bn_silu_tab"}
+SITE_PMC_PREFIX = {"conv2": "void gemm_ns<2, 2, 32", "ffn2": "void gemm_ns_tab<1, 1, 64", "attn": "rel_attention_stream_tab", "dwconv": "dwconv_bn_silu_tab"}
+
+
+def pmc_traffic(site):
+    """HBM-side bytes per launch of the site's kernel from the committed PMC summary (profiles/, rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes of this same command, tools/pmc_summary.py); None if there is no summary for it."""
+    pref = SITE_PMC_PREFIX.get(site)
+    if pref is None:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    cands = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith("pmc_traffic.json")) if os.path.isdir(os.path.join(here, "profiles")) else []
+    if not cands:
+        return None
+    d = json.load(open(os.path.join(here, "profiles", cands[-1])))
+    for k, v in d["kernels"].items():
+        if k.startswith(pref):
+            return {"traffic_bytes_per_launch": v["traffic_bytes_per_launch"], "source": f"profiles/{cands[-1]} (PMC, separate passes; 2 x FETCH_SIZE + WRITE_SIZE)"}
+    return None
+
+
 def site_flops_bytes(site, B, plan):
     """Algorithmic FLOPs (2*MAC) and bytes of all launches of one site in one step."""
     fl = by = 0.0
@@ -253,12 +277,19 @@ def main():
         hbm = args.site in ("attn", "dwconv")
         if hbm:
             ach = by * args.steps / site_s / 1e9
-            roofline = {"bound": "hbm", "kernel": f"{args.site}", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+            roofline = {"bound": "hbm", "kernel": SITE_KERNEL.get(args.site, args.site), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
         else:
             ach = fl * args.steps / site_s / 1e12
-            roofline = {"bound": "mfma", "kernel": f"gemm32 @ {args.site}", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": SITE_KERNEL.get(args.site, args.site), "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+        lps = site_launches / args.steps      # launches of this site per step (the wavefront schedule groups many chunk-layer pairs per launch)
+        roofline["algorithmic_flops_per_launch"] = round(fl / lps)
+        roofline["algorithmic_bytes_per_launch"] = round(by / lps)
+        tr = pmc_traffic(args.site)
+        if tr is not None:
+            roofline["traffic"] = tr["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = tr["source"]
         roofline["avg_launch_us"] = round(avg_s * 1e6, 2)
         roofline["launches_timed"] = int(site_launches)
         roofline["share_of_step"] = round(site_ms * 1e-3 / elapsed, 4)
