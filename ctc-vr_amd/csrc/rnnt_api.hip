@@ -64,6 +64,7 @@ struct rnnt_ctx {
     unsigned long long* key = nullptr;
     int* dec_ctrl = nullptr;   // persistent decoder control block: [0] frames_ready, [1] error, [2] evaluations, [3..6] cooperative decoder
     int use_persistent = 1;
+    int attn_stream = 1;       // RNNT_ATTN_STREAM=0: LDS-tiled attention kernel for every chunk
     int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
     float* coop_z = nullptr; int* coop_st2 = nullptr; unsigned long long* coop_key2 = nullptr;
@@ -335,16 +336,15 @@ int build_layer(rnnt_ctx* ctx, int l, int B, int tq, int T2, int kv_row0, int po
 }
 
 // streaming chunks (<= 4 new frames): direct-stream kernel; dynamic LDS = 4 score rows + the PV partial sums
-static bool attn_stream_ok(int tq, int T2) {
-    static const int on = getenv("RNNT_ATTN_STREAM") ? atoi(getenv("RNNT_ATTN_STREAM")) : 1;
-    return on && tq <= 4 && T2 >= 1 && T2 <= 4096;
+static bool attn_stream_ok(const rnnt_ctx* ctx, int tq, int T2) {
+    return ctx->attn_stream && tq <= 4 && T2 >= 1 && T2 <= 4096;
 }
 static int attn_t2cap(int T2) { return (T2 + 63) / 64 * 64; }
 static size_t attn_stream_lds(int t2cap) { return (size_t)(4 * t2cap + 16 * 4 * RNNT_DK) * sizeof(float); }
 
 int launch_attn(rnnt_ctx* ctx, hipStream_t s, const AttnP& a, int B) {
     ProfScope prof(ctx, s, TAG_ATTN);
-    if (attn_stream_ok(a.tq, a.T2)) {
+    if (attn_stream_ok(ctx, a.tq, a.T2)) {
         const int cap = attn_t2cap(a.T2);
         hipLaunchKernelGGL(rel_attention_stream, dim3(B * RNNT_H), dim3(256), attn_stream_lds(cap), s, a, cap);
         LAUNCHCHK("rel_attention_stream");
@@ -705,6 +705,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     if (const char* ng = getenv("RNNT_NO_GRAPH")) ctx->use_graphs = (ng[0] == '1') ? 0 : 1;
     if (const char* pe = getenv("RNNT_PERSISTENT")) ctx->use_persistent = (pe[0] == '0') ? 0 : 1;
     if (const char* ce = getenv("RNNT_COOP")) ctx->use_coop = (ce[0] == '0') ? 0 : 1;
+    if (const char* ae = getenv("RNNT_ATTN_STREAM")) ctx->attn_stream = (ae[0] == '0') ? 0 : 1;
     const int B = cfg->max_streams;
     ctx->tmax = sub_len(cfg->max_chunk_frames);
     ctx->t1max = sub1_len(cfg->max_chunk_frames);
@@ -1258,7 +1259,7 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
                 if ((rc = launch_gemm_tab(ctx, s, ctx->wf_gtab + q.off, q.n, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
             } else if (q.type == 10) {
                 ProfScope prof(ctx, s, TAG_ATTN);
-                if (attn_stream_ok(q.maxM, q.maxT2 > 0 ? q.maxT2 : 1)) {
+                if (attn_stream_ok(ctx, q.maxM, q.maxT2 > 0 ? q.maxT2 : 1)) {
                     const int cap = attn_t2cap(q.maxT2);
                     hipLaunchKernelGGL(rel_attention_stream_tab, dim3(B * RNNT_H, 1, q.n), dim3(256), attn_stream_lds(cap), s, ctx->wf_atab + q.off, cap);
                     LAUNCHCHK("rel_attention_stream_tab");

@@ -239,6 +239,49 @@ def test_wavefront_encoder_matches_chunk_by_chunk(np_state_dict):
     assert maxdiff(enc_seq[0], g0["enc_out"]) < LOGIT_TOL
 
 
+def test_full_size_properties(np_state_dict):
+    """BASELINE configs[1] at full size (64 streams x 1000 frames, chunk 16), size-independent properties:
+    whole-utterance call == per-chunk API, run-to-run determinism, independence of a stream from its batch
+    position and neighbours, and two of the streams against the CPU oracle (the bench checks eight)."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    sd_np = np_state_dict(0)
+    B = 64
+    x_cpu = torch.from_numpy(T.synth_fbank(B, 1000, seed=1234))
+    x = x_cpu.cuda().contiguous()
+    sb = StreamingBatch(sd_np, B, max_chunk_frames=24, max_cache_frames=200, max_enc_frames=200, max_tokens=1900)
+    pipelined = sb.decode_script(x, 16, pipelined=True)
+    assert sb.decode_script(x, 16, pipelined=True) == pipelined                      # deterministic
+    assert sb.decode_script(x, 16, per_chunk_decode=True) == pipelined               # per-chunk API, same tokens
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(7))
+    permuted = sb.decode_script(x[perm.cuda()].contiguous(), 16, pipelined=True)
+    for i in range(B):
+        assert permuted[i] == pipelined[int(perm[i])], i                              # no cross-stream leakage
+    counts = [len(t) for t in pipelined]
+    assert min(counts) > 0 and max(counts) < 1880
+    sd = O.to_torch_sd(sd_np)
+    for b in (int(np.argmax(counts)), int(np.argmin(counts))):                         # the busiest and the quietest stream
+        want, _, _ = O.decode_script_greedy(sd, x_cpu[b:b + 1], 16)
+        assert pipelined[b] == want, b
+
+
+@pytest.mark.parametrize("env", [{"RNNT_PERSISTENT": "0"}, {"RNNT_COOP": "1"}, {"RNNT_ATTN_STREAM": "0"}])
+def test_alternative_decoder_paths(np_state_dict, env, monkeypatch):
+    """The launched decode path (what a serialising profiler falls back to), the cooperative decoder and the
+    LDS-tiled attention produce the reference's tokens too."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
+    syn = torch.from_numpy(T.synth_fbank(2, 1000))
+    x = torch.stack([syn[i % 2] for i in range(6)]).cuda().contiguous()
+    sb = StreamingBatch(np_state_dict(0), 6, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256)
+    for mode in ({"pipelined": True}, {"per_chunk_decode": True}):
+        toks = sb.decode_script(x, 16, **mode)
+        for i in range(6):
+            assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (env, mode, i)
+
+
 def test_fresh_inputs_against_oracle(np_state_dict):
     """Seeded inputs no fixture covers: HIP (B=4, chunk 24) vs the CPU oracle run stream by stream."""
     from oracle import rnnt_oracle as O
