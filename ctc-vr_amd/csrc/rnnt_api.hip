@@ -92,7 +92,10 @@ struct rnnt_ctx {
     GemmP* wf_gtab = nullptr; AttnP* wf_atab = nullptr; DwP* wf_dtab = nullptr; LnP* wf_ltab = nullptr;
     size_t wf_gcap = 0, wf_acap = 0, wf_dcap = 0, wf_lcap = 0;
     hipStream_t dec_stream = nullptr;          // decode runs here while the encoder wavefront runs on the caller's stream
-    hipStream_t enc_stream = nullptr;          // experiment (RNNT_DEC_CUS): encoder on the complementary CU mask
+    hipStream_t grp_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // layer groups 1.. of the wavefront (group 0 = caller's stream)
+    hipStream_t sub_stream = nullptr;          // subsampling slabs
+    int wf_groups = 2, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4), RNNT_WF_SUB_ASYNC
+    std::vector<hipEvent_t> ev_pool;
     hipStream_t cap_stream = nullptr;          // stream-capture scratch stream
     struct DecGraph { int n_streams, k; hipGraphExec_t exec; };
     std::vector<DecGraph> dec_graphs;          // K greedy steps captured once per (n_streams, K)
@@ -706,6 +709,8 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     if (const char* pe = getenv("RNNT_PERSISTENT")) ctx->use_persistent = (pe[0] == '0') ? 0 : 1;
     if (const char* ce = getenv("RNNT_COOP")) ctx->use_coop = (ce[0] == '0') ? 0 : 1;
     if (const char* ae = getenv("RNNT_ATTN_STREAM")) ctx->attn_stream = (ae[0] == '0') ? 0 : 1;
+    if (const char* ge = getenv("RNNT_WF_GROUPS")) { const int g = atoi(ge); ctx->wf_groups = g < 1 ? 1 : (g > 4 ? 4 : g); }
+    if (const char* se = getenv("RNNT_WF_SUB_ASYNC")) ctx->wf_sub_async = (se[0] == '0') ? 0 : 1;
     const int B = cfg->max_streams;
     ctx->tmax = sub_len(cfg->max_chunk_frames);
     ctx->t1max = sub1_len(cfg->max_chunk_frames);
@@ -771,7 +776,9 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     if (ctx->dec_stream) (void)hipStreamDestroy(ctx->dec_stream);
     for (auto& g : ctx->dec_graphs) (void)hipGraphExecDestroy(g.exec);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
-    if (ctx->enc_stream) (void)hipStreamDestroy(ctx->enc_stream);
+    for (hipStream_t x : ctx->grp_stream) if (x) (void)hipStreamDestroy(x);
+    if (ctx->sub_stream) (void)hipStreamDestroy(ctx->sub_stream);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void* wf[] = {ctx->wf_x, ctx->wf_h, ctx->wf_q, ctx->wf_a, ctx->wf_d, ctx->wf_y1, ctx->wf_y2, ctx->wf_starts, ctx->wf_gtab, ctx->wf_atab,
                   ctx->wf_dtab, ctx->wf_ltab};
     for (void* q : wf)
@@ -1131,14 +1138,49 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         if ((rc = dmalloc(ctx, &ctx->wf_y2, (size_t)ctx->wf_slab * Mmax * RNNT_FSUB * D))) return rc;
     }
     if ((rc = grow(ctx, &ctx->wf_starts, &ctx->wf_starts_cap, (size_t)C))) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->wf_starts, chunk_start, C * sizeof(int), hipMemcpyHostToDevice, s));
+    // ---- streams ---------------------------------------------------------------------------------------------------
+    // The layers are split into G groups of consecutive layers, one HIP stream each (group 0 = the caller's stream):
+    // within a group the stages are stream-ordered; group g+1's stage st+1 waits for group g's stage st (layer lo(g+1)
+    // of chunk c needs layer lo(g+1)-1 of the same chunk, nothing else crosses a group).  Kernels of different groups
+    // run concurrently, so one group's MFMA phases fill the other's prologue / epilogue / launch ramps, and the
+    // subsampling (big-M conv2, MFMA-bound) runs on its own stream under the latency-bound stages instead of in front
+    // of them -- the first frames reach the decoder ~4 ms earlier.
+    const int G = ctx->wf_groups;
+    hipStream_t gs[4] = {s, s, s, s};
+    for (int g = 1; g < G; ++g) {
+        if (!ctx->grp_stream[g]) HIPCHK(hipStreamCreateWithFlags(&ctx->grp_stream[g], hipStreamNonBlocking));
+        gs[g] = ctx->grp_stream[g];
+    }
+    if (ctx->wf_sub_async && !ctx->sub_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->sub_stream, hipStreamNonBlocking));
+    hipStream_t ss = ctx->wf_sub_async ? ctx->sub_stream : s;
+    size_t ev_next = 0;
+    auto new_event = [&](hipEvent_t* out) -> int {
+        if (ev_next == ctx->ev_pool.size()) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_pool.push_back(e);
+        }
+        *out = ctx->ev_pool[ev_next++];
+        return RNNT_OK;
+    };
+    hipEvent_t e_in;
+    if ((rc = new_event(&e_in))) return rc;
+    HIPCHK(hipEventRecord(e_in, s));                       // everything the caller enqueued before this call
+    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(gs[g], e_in, 0));
+    if (ss != s) HIPCHK(hipStreamWaitEvent(ss, e_in, 0));
     // ---- (a) subsampling, runs of equal-length chunks in slabs ------------------------------------------
+    HIPCHK(hipMemcpyAsync(ctx->wf_starts, chunk_start, C * sizeof(int), hipMemcpyHostToDevice, ss));
+    std::vector<hipEvent_t> slab_ev(C, nullptr);           // set on the first chunk of every slab
     for (int c0 = 0; c0 < C;) {
         int c1 = c0 + 1;
         while (c1 < C && ci[c1].len == ci[c0].len && c1 - c0 < ctx->wf_slab) ++c1;
-        if ((rc = run_subsample(ctx, s, fbank_dev, B, total_frames, ci[c0].len, ctx->wf_starts + c0, c1 - c0, ctx->wf_y1, ctx->wf_y2,
+        if ((rc = run_subsample(ctx, ss, fbank_dev, B, total_frames, ci[c0].len, ctx->wf_starts + c0, c1 - c0, ctx->wf_y1, ctx->wf_y2,
                                 ctx->wf_x + ci[c0].xoff * D)))
             return rc;
+        if (ss != s) {
+            if ((rc = new_event(&slab_ev[c0]))) return rc;
+            HIPCHK(hipEventRecord(slab_ev[c0], ss));
+        }
         c0 = c1;
     }
     // ---- (b) wavefront tables ---------------------------------------------------------------------------------
@@ -1197,28 +1239,22 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     static const int gN[8] = {FF, D, D, D, 2 * D, D, FF, D};
     static const int gK[8] = {D, FF, D, D, D, D, D, FF};
     static const int gTag[8] = {TAG_FFN1, TAG_FFN2, TAG_QKV, TAG_ATTN_OUT, TAG_PW1, TAG_PW2, TAG_FFN1, TAG_FFN2};
+    if (G > 1) {                                            // the other groups read the tables copied on s
+        hipEvent_t e_tab;
+        if ((rc = new_event(&e_tab))) return rc;
+        HIPCHK(hipEventRecord(e_tab, s));
+        for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(gs[g], e_tab, 0));
+    }
+    hipStream_t sl = gs[G - 1];                             // the stream the last layer runs on
     // decode stream + events (greedy != 0): chunk c's frames are decodable once its layer-11 stage, after_norm and
-    // joint.enc_ffn projection are done; the greedy steps run on ctx->dec_stream concurrently with later stages.
-    hipStream_t s2 = s, caller = nullptr;
+    // joint.enc_ffn projection are done; the decoder runs on ctx->dec_stream concurrently with later stages.
+    hipStream_t s2 = s;
     bool resident = false;
     if (greedy) {
-        if (!ctx->dec_stream) {   // decode = the latency-critical dependent chain: highest stream priority
+        if (!ctx->dec_stream) {   // decode = the latency-critical dependent chain: highest stream priority (own hardware queue)
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            const char* pe = getenv("RNNT_DEC_PRIO");
-            const int prio = (pe && pe[0] == '0') ? lo : hi;
-            const char* me = getenv("RNNT_DEC_CUS");   // experiment: n CUs (every 256/n-th) reserved for decode, the rest for the encoder
-            const int ncu = me ? atoi(me) : 0;
-            if (ncu > 0) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, inv[8];
-                const int step = 256 / ncu;
-                for (int i = 0; i < 256; i += step) mask[i >> 5] |= 1u << (i & 31);
-                for (int i = 0; i < 8; ++i) inv[i] = ~mask[i];
-                HIPCHK(hipExtStreamCreateWithCUMask(&ctx->dec_stream, 8, mask));
-                HIPCHK(hipExtStreamCreateWithCUMask(&ctx->enc_stream, 8, inv));
-            } else {
-                HIPCHK(hipStreamCreateWithPriority(&ctx->dec_stream, hipStreamNonBlocking, prio));
-            }
+            HIPCHK(hipStreamCreateWithPriority(&ctx->dec_stream, hipStreamNonBlocking, hi));
         }
         s2 = ctx->dec_stream;
         while ((int)ctx->wf_ev.size() < C + 1) {
@@ -1226,101 +1262,97 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->wf_ev.push_back(e);
         }
-        while ((int)ctx->wf_evd.size() < C) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->wf_evd.push_back(e);
-        }
         ctx->pinned[8] = 0;
-        if (ctx->use_persistent && ctx->overlap_ok < 0 && (rc = probe_overlap(ctx, s, s2))) return rc;
+        if (ctx->use_persistent && ctx->overlap_ok < 0) {   // the resident decoder must not block ANY stream the encoder uses
+            if ((rc = probe_overlap(ctx, s, s2))) return rc;
+            for (int g = 1; g < G && ctx->overlap_ok == 1; ++g)
+                if ((rc = probe_overlap(ctx, gs[g], s2))) return rc;
+            if (ss != s && ctx->overlap_ok == 1 && (rc = probe_overlap(ctx, ss, s2))) return rc;
+        }
         resident = ctx->use_persistent && ctx->overlap_ok == 1;
         if (resident && (rc = init_decoder_ctrl(ctx, s, ctx->frames_buffered))) return rc;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s));          // everything enqueued before this call (reset, earlier decode)
         HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[C], 0));
+        if (sl != s) HIPCHK(hipStreamWaitEvent(sl, ctx->wf_ev[C], 0));   // publish_frames comes after the control block's init
         if (resident && (rc = launch_persistent_decoder(ctx, s2, fb))) return rc;
-        if (ctx->enc_stream) {                              // experiment: move the wavefront to the masked encoder stream
-            HIPCHK(hipStreamWaitEvent(ctx->enc_stream, ctx->wf_ev[C], 0));
-            caller = s;
-            s = ctx->enc_stream;
-        }
     }
     int dec_steps = 0;
-    std::vector<int> extra_hist(C, 0);
     const int fb0 = ctx->frames_buffered;
-    size_t qi = 0;
     static const bool timing = getenv("RNNT_TIMING") != nullptr;
     double t_enc = 0, t_dec = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tl = now();
+    std::vector<hipEvent_t> grp_ev((size_t)G * (C + L), nullptr);   // [g][st]: group g finished its part of stage st
     for (int st = 0; st < C + L - 1; ++st) {
-        for (int j = 0; j < 11 && qi < seq.size(); ++j, ++qi) {
-            const Launch& q = seq[qi];
-            if (q.type < 8) {
-                if ((rc = launch_gemm_tab(ctx, s, ctx->wf_gtab + q.off, q.n, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
-            } else if (q.type == 10) {
-                ProfScope prof(ctx, s, TAG_ATTN);
-                if (attn_stream_ok(ctx, q.maxM, q.maxT2 > 0 ? q.maxT2 : 1)) {
-                    const int cap = attn_t2cap(q.maxT2);
-                    hipLaunchKernelGGL(rel_attention_stream_tab, dim3(B * RNNT_H, 1, q.n), dim3(256), attn_stream_lds(cap), s, ctx->wf_atab + q.off, cap);
-                    LAUNCHCHK("rel_attention_stream_tab");
-                    continue;
+        const int lmin = st - C + 1 > 0 ? st - C + 1 : 0, lmax = st < L - 1 ? st : L - 1;   // layers with a chunk in this stage
+        for (int g = 0; g < G; ++g) {
+            const int lo = g * L / G, hi = (g + 1) * L / G;                                  // layers [lo, hi) of this group
+            const int l0 = lo > lmin ? lo : lmin, l1 = (hi - 1) < lmax ? (hi - 1) : lmax;
+            if (l0 > l1) continue;
+            const int p0 = l0 - lmin, pn = l1 - l0 + 1;                                      // pairs [p0, p0 + pn) of the stage
+            hipStream_t x = gs[g];
+            if (l0 == 0 && slab_ev[st]) HIPCHK(hipStreamWaitEvent(x, slab_ev[st], 0));      // layer 0 of chunk st: its slab is subsampled
+            if (g > 0 && l0 == lo && st > 0 && grp_ev[(size_t)(g - 1) * (C + L) + st - 1])
+                HIPCHK(hipStreamWaitEvent(x, grp_ev[(size_t)(g - 1) * (C + L) + st - 1], 0));
+            for (int j = 0; j < 11; ++j) {
+                const Launch& q = seq[(size_t)st * 11 + j];
+                if (q.type < 8) {
+                    const int mult = q.type == 2 ? 3 : 1;
+                    if ((rc = launch_gemm_tab(ctx, x, ctx->wf_gtab + q.off + mult * p0, mult * pn, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
+                } else if (q.type == 10) {
+                    ProfScope prof(ctx, x, TAG_ATTN);
+                    if (attn_stream_ok(ctx, q.maxM, q.maxT2 > 0 ? q.maxT2 : 1)) {
+                        const int cap = attn_t2cap(q.maxT2);
+                        hipLaunchKernelGGL(rel_attention_stream_tab, dim3(B * RNNT_H, 1, pn), dim3(256), attn_stream_lds(cap), x, ctx->wf_atab + q.off + p0, cap);
+                        LAUNCHCHK("rel_attention_stream_tab");
+                        continue;
+                    }
+                    const int nq = q.maxM <= 4 ? 1 : (q.maxM <= 8 ? 2 : 4);
+                    dim3 grid(B * RNNT_H, (q.maxM + 4 * nq - 1) / (4 * nq), pn);
+                    if (nq == 1) hipLaunchKernelGGL(rel_attention_tab<1>, grid, dim3(256), 0, x, ctx->wf_atab + q.off + p0);
+                    else if (nq == 2) hipLaunchKernelGGL(rel_attention_tab<2>, grid, dim3(256), 0, x, ctx->wf_atab + q.off + p0);
+                    else hipLaunchKernelGGL(rel_attention_tab<4>, grid, dim3(256), 0, x, ctx->wf_atab + q.off + p0);
+                    LAUNCHCHK("rel_attention_tab");
+                } else if (q.type == 11) {
+                    ProfScope prof(ctx, x, TAG_DWCONV);
+                    hipLaunchKernelGGL(dwconv_bn_silu_tab, dim3(grid_for((long long)q.maxM * D), 1, pn), dim3(256), 0, x, ctx->wf_dtab + q.off + p0);
+                    LAUNCHCHK("dwconv_bn_silu_tab");
+                } else {
+                    hipLaunchKernelGGL(layer_norm_tab, dim3((q.maxM + 3) / 4, 1, pn), dim3(256), 0, x, ctx->wf_ltab + q.off + p0);
+                    LAUNCHCHK("layer_norm_tab");
                 }
-                const int nq = q.maxM <= 4 ? 1 : (q.maxM <= 8 ? 2 : 4);
-                dim3 grid(B * RNNT_H, (q.maxM + 4 * nq - 1) / (4 * nq), q.n);
-                if (nq == 1) hipLaunchKernelGGL(rel_attention_tab<1>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
-                else if (nq == 2) hipLaunchKernelGGL(rel_attention_tab<2>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
-                else hipLaunchKernelGGL(rel_attention_tab<4>, grid, dim3(256), 0, s, ctx->wf_atab + q.off);
-                LAUNCHCHK("rel_attention_tab");
-            } else if (q.type == 11) {
-                ProfScope prof(ctx, s, TAG_DWCONV);
-                hipLaunchKernelGGL(dwconv_bn_silu_tab, dim3(grid_for((long long)q.maxM * D), 1, q.n), dim3(256), 0, s, ctx->wf_dtab + q.off);
-                LAUNCHCHK("dwconv_bn_silu_tab");
-            } else {
-                hipLaunchKernelGGL(layer_norm_tab, dim3((q.maxM + 3) / 4, 1, q.n), dim3(256), 0, s, ctx->wf_ltab + q.off);
-                LAUNCHCHK("layer_norm_tab");
+            }
+            if (g < G - 1 && l1 == hi - 1) {                // the next group's first layer reads this group's last layer
+                hipEvent_t e;
+                if ((rc = new_event(&e))) return rc;
+                HIPCHK(hipEventRecord(e, x));
+                grp_ev[(size_t)g * (C + L) + st] = e;
             }
         }
         const int c = st - (L - 1);   // chunk whose last block just ran
         if (c < 0) continue;
         // (c) after_norm straight into the frame buffer + joint.enc_ffn projection of the chunk's frames
-        if ((rc = launch_ln(ctx, s, LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
-                                        (long long)ctx->fstride * D, (long long)D}))) return rc;
+        if ((rc = launch_ln(ctx, sl, LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
+                                         (long long)ctx->fstride * D, (long long)D}))) return rc;
         {
             const int F = ci[c].tq;
             GemmP g = plain_gemm(ctx->encbuf + (size_t)ci[c].fpos * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * F, D, D);
             g.a_n1 = F; g.a_n2 = F; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;
             g.c_n = F; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ci[c].fpos; g.c_mod = BIG; g.c_s1 = D;
-            if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
+            if ((rc = launch_gemm(ctx, sl, 0, &g, 1, TAG_ENC_PROJ))) return rc;
         }
         if (timing) { double t = now(); t_enc += t - tl; tl = t; }
         if (greedy && resident) {   // the resident decoder sees the chunk's frames as soon as this lands
-            hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, ci[c].fpos + ci[c].tq);
+            hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, sl, ctx->dec_ctrl, ci[c].fpos + ci[c].tq);
             LAUNCHCHK("publish_frames");
         } else if (greedy) {
-            HIPCHK(hipEventRecord(ctx->wf_ev[c], s));
+            HIPCHK(hipEventRecord(ctx->wf_ev[c], sl));
             HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c], 0));
-            // Step budget of this chunk: its frames + a little slack + the backlog the slowest stream has built up
-            // ("runaway" streams emit up to n_steps symbols per frame).  The backlog (frames behind, written to pinned
-            // memory by greedy_decide) is read LAG chunks late, so the extra steps already enqueued inside that window
-            // are subtracted (delay-compensated feedback; without it the stale backlog is re-added every chunk).
+            // launched decode path: this chunk's frames + a little slack per chunk, in hipGraph-captured batches
             static const int slack = getenv("RNNT_DEC_SLACK") ? atoi(getenv("RNNT_DEC_SLACK")) : 8;
-            static const int lag = getenv("RNNT_DEC_LAG") ? atoi(getenv("RNNT_DEC_LAG")) : 0;
-            static const int kper = getenv("RNNT_DEC_K") ? atoi(getenv("RNNT_DEC_K")) : 4;
-            int extra = 0;
-            if (lag > 0 && c >= lag) {
-                HIPCHK(hipEventSynchronize(ctx->wf_evd[c - lag]));
-                const int backlog = *(volatile int*)(ctx->pinned + 8);
-                int pending = 0;
-                for (int j = c - lag + 1; j < c; ++j) pending += extra_hist[j];
-                extra = backlog * kper - pending;
-                if (extra < 0) extra = 0;
-                if (extra > 48) extra = 48;
-            }
-            extra_hist[c] = extra;
-            int budget = ci[c].tq + slack + extra;
+            int budget = ci[c].tq + slack;
             budget = (budget + 3) / 4 * 4;   // few distinct graph sizes
             if ((rc = greedy_steps(ctx, s2, budget, ci[c].fpos + ci[c].tq))) return rc;
-            HIPCHK(hipEventRecord(ctx->wf_evd[c], s2));
             dec_steps += budget;
             if (timing) { double t = now(); t_dec += t - tl; tl = t; }
         }
@@ -1328,19 +1360,32 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     if (timing) fprintf(stderr, "[rnnt timing] host enqueue: encoder stages %.2f ms, decode batches %.2f ms\n", t_enc, t_dec);
     if (frames_out) *frames_out = fb - fb0;
     ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
+    // ---- join: the caller's stream continues after every internal stream ---------------------------------------------
+    for (int g = 1; g < G; ++g) {
+        hipEvent_t e;
+        if ((rc = new_event(&e))) return rc;
+        HIPCHK(hipEventRecord(e, gs[g]));
+        HIPCHK(hipStreamWaitEvent(s, e, 0));
+    }
+    if (ss != s) {
+        hipEvent_t e;
+        if ((rc = new_event(&e))) return rc;
+        HIPCHK(hipEventRecord(e, ss));
+        HIPCHK(hipStreamWaitEvent(s, e, 0));
+    }
     if (greedy && resident) {
         double t_e = 0;
         if (timing) { (void)hipStreamSynchronize(s); t_e = now(); }
         if ((rc = finish_persistent_decoder(ctx, s2))) return rc;      // synchronises the decode stream (=> encoder done too)
-        if (timing) fprintf(stderr, "[rnnt timing] decoder finished %.3f ms after the encoder stream drained\n", now() - t_e);
+        if (timing) fprintf(stderr, "[rnnt timing] decoder finished %.3f ms after the encoder streams drained\n", now() - t_e);
         ctx->frames_decoded = fb;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));
-        HIPCHK(hipStreamWaitEvent(caller ? caller : s, ctx->wf_ev[C], 0));
+        HIPCHK(hipStreamWaitEvent(s, ctx->wf_ev[C], 0));
     } else if (greedy) {
         if ((rc = greedy_drain(ctx, s2, fb, dec_steps))) return rc;   // synchronises the decode stream (=> encoder done too)
         ctx->frames_decoded = fb;
         HIPCHK(hipEventRecord(ctx->wf_ev[C], s2));                    // later work on the caller's stream sees the decode
-        HIPCHK(hipStreamWaitEvent(caller ? caller : s, ctx->wf_ev[C], 0));
+        HIPCHK(hipStreamWaitEvent(s, ctx->wf_ev[C], 0));
     }
     return RNNT_OK;
 }
