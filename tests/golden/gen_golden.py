@@ -251,10 +251,48 @@ def gen_full(inputs):
     save("full_ex6_seed0.npz", out=f32(y), mask=m.numpy())
 
 
+def gen_cer():
+    """Edit-distance cases for the CER harness: the reference's own calculate_cer (online_rnnt_eval.py:11-56) run on
+    seeded random token lists.  The module cannot be imported (torchaudio/librosa at import time, py3.12-only
+    f-strings), so only that one function is compiled from the parsed source and executed here."""
+    import ast
+    import re
+    src = open("/root/reference/online_rnnt_eval.py", encoding="utf-8").read()
+    src = re.sub(r"\{\n\s+", "{", src)
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "calculate_cer"]
+    ns = {}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "online_rnnt_eval.py", "exec"), ns)
+    rng = np.random.Generator(np.random.Philox(99))
+    n_cases, maxlen = 200, 24
+    hyp = np.zeros((n_cases, maxlen), np.int32)
+    refs = np.zeros((n_cases, maxlen), np.int32)
+    lens = np.zeros((n_cases, 2), np.int32)
+    res = np.zeros((n_cases, 5), np.float64)
+    for i in range(n_cases):
+        vocab = int(rng.integers(2, 9))                      # small alphabets: many equal-cost alignments
+        a = rng.integers(0, vocab, int(rng.integers(0, maxlen + 1))).tolist()
+        if i % 3 == 0:                                        # a noisy copy of the hypothesis
+            b = [t for t in a if rng.random() > 0.2]
+            b = [int(rng.integers(0, vocab)) if rng.random() < 0.2 else t for t in b]
+            b = b[:maxlen]
+        else:
+            b = rng.integers(0, vocab, int(rng.integers(0, maxlen + 1))).tolist()
+        hyp[i, :len(a)] = a
+        refs[i, :len(b)] = b
+        lens[i] = (len(a), len(b))
+        res[i] = ns["calculate_cer"](a, b)
+    save("cer_cases.npz", hyp=hyp, ref=refs, lens=lens, result=res)
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
+    if len(sys.argv) > 1 and sys.argv[1] == "cer":
+        gen_cer()
+        sys.exit(0)
     inp = gen_inputs()
     gen_modules(0, inp)
     gen_modules(1, inp)
     gen_streams(inp)
     gen_full(inp)
+    gen_cer()
