@@ -96,6 +96,10 @@ struct rnnt_ctx {
     hipStream_t sub_stream = nullptr;          // subsampling slabs
     int wf_groups = 2, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4), RNNT_WF_SUB_ASYNC
     std::vector<hipEvent_t> ev_pool;
+    // feature front-end (rnnt_fbank): DFT / mel matrices for (fb_rate, fb_nfft) and grow-only work buffers
+    float *fb_dft = nullptr, *fb_mel = nullptr, *fb_pad = nullptr, *fb_spec = nullptr, *fb_pow = nullptr;
+    size_t fb_pad_cap = 0, fb_spec_cap = 0, fb_pow_cap = 0;
+    int fb_rate = 0, fb_nfft = 0;
     hipStream_t cap_stream = nullptr;          // stream-capture scratch stream
     struct DecGraph { int n_streams, k; hipGraphExec_t exec; };
     std::vector<DecGraph> dec_graphs;          // K greedy steps captured once per (n_streams, K)
@@ -779,6 +783,7 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     for (hipStream_t x : ctx->grp_stream) if (x) (void)hipStreamDestroy(x);
     if (ctx->sub_stream) (void)hipStreamDestroy(ctx->sub_stream);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (float* q : {ctx->fb_dft, ctx->fb_mel, ctx->fb_pad, ctx->fb_spec, ctx->fb_pow}) if (q) (void)hipFree(q);
     void* wf[] = {ctx->wf_x, ctx->wf_h, ctx->wf_q, ctx->wf_a, ctx->wf_d, ctx->wf_y1, ctx->wf_y2, ctx->wf_starts, ctx->wf_gtab, ctx->wf_atab,
                   ctx->wf_dtab, ctx->wf_ltab};
     for (void* q : wf)
@@ -1632,6 +1637,80 @@ int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_h
     HIPCHK(hipMemcpyAsync(ids_host, ids, rows * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (frames_out) *frames_out = tq;
+    return RNNT_OK;
+}
+
+// Feature front-end on the device: the reference's extract_audio_features (data/dataloader.py:15-41) =
+// torchaudio MelSpectrogram(sample_rate, n_fft, n_mels=80, hop_length=512, window_fn=hamming_window, power=2.0)
+// [defaults: win_length = n_fft, center=True, pad_mode="reflect", onesided, HTK mel scale, norm=None, f_min=0,
+// f_max=sample_rate/2] followed by AmplitudeToDB() [power: 10*log10(clamp(x, 1e-10)), ref 1.0, no top_db].
+// wave_dev [B][n_samples] float32 mono -> out_dev [B][1 + n_samples/512][80].  No model weights are needed.
+int rnnt_fbank(rnnt_ctx* ctx, const float* wave_dev, int32_t B, int32_t n_samples, int32_t sample_rate, int32_t n_fft, float* out_dev,
+               int32_t* frames_out, void* stream) {
+    if (!ctx || !wave_dev || !out_dev) return fail(ctx, RNNT_ERR_ARG, "rnnt_fbank: null argument");
+    const int hop = 512, n_mels = 80;
+    if (B < 1 || sample_rate < 2 || n_fft < 64 || n_fft > 4096 || n_fft % 64 != 0)
+        return fail(ctx, RNNT_ERR_SHAPE, "rnnt_fbank: B=%d sample_rate=%d n_fft=%d (n_fft must be a multiple of 64 in [64, 4096])", B, sample_rate, n_fft);
+    if (n_samples <= n_fft / 2) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_fbank: reflect padding needs more than n_fft/2 = %d samples (got %d)", n_fft / 2, n_samples);
+    hipStream_t s = (hipStream_t)stream;
+    const int nfreq = n_fft / 2 + 1;
+    const int n2p = (2 * nfreq + 63) / 64 * 64;          // DFT output columns (re, im interleaved), padded
+    const int kp = (nfreq + 63) / 64 * 64;               // K of the mel projection, padded with zero columns
+    const int T = 1 + n_samples / hop;
+    const long long pstride = ((long long)n_samples + n_fft + 3) / 4 * 4;   // padded signal per stream, 16-B aligned rows
+    const long long M = (long long)B * T;
+    if (M > 0x7fffffffLL / 8) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_fbank: %lld frames in one call", M);
+    int rc;
+    if (ctx->fb_rate != sample_rate || ctx->fb_nfft != n_fft) {   // matrices in double on the host, once per (rate, n_fft)
+        HIPCHK(hipStreamSynchronize(s));
+        if (ctx->fb_dft) { (void)hipFree(ctx->fb_dft); ctx->fb_dft = nullptr; }
+        if (ctx->fb_mel) { (void)hipFree(ctx->fb_mel); ctx->fb_mel = nullptr; }
+        if ((rc = dmalloc(ctx, &ctx->fb_dft, (size_t)n2p * n_fft))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->fb_mel, (size_t)n_mels * kp))) return rc;
+        const double pi = 3.14159265358979323846;
+        std::vector<float> dft((size_t)n2p * n_fft, 0.f), mel((size_t)n_mels * kp, 0.f);
+        std::vector<double> win(n_fft);
+        for (int n = 0; n < n_fft; ++n) win[n] = 0.54 - 0.46 * cos(2.0 * pi * n / n_fft);   // torch.hamming_window (periodic)
+        for (int k = 0; k < nfreq; ++k)
+            for (int n = 0; n < n_fft; ++n) {
+                const long long kn = ((long long)k * n) % n_fft;                              // exact phase reduction
+                const double ph = 2.0 * pi * (double)kn / n_fft;
+                dft[(size_t)(2 * k) * n_fft + n] = (float)(win[n] * cos(ph));
+                dft[(size_t)(2 * k + 1) * n_fft + n] = (float)(-win[n] * sin(ph));
+            }
+        // torchaudio.functional.melscale_fbanks(n_freqs, 0, rate/2, 80, rate, norm=None, mel_scale="htk")
+        const double fmax = (double)(sample_rate / 2);   // all_freqs = linspace(0, sample_rate // 2, n_freqs)
+        const double m_max = 2595.0 * log10(1.0 + fmax / 700.0);             // f_max = float(sample_rate // 2)
+        std::vector<double> fpts(n_mels + 2);
+        for (int i = 0; i < n_mels + 2; ++i) fpts[i] = 700.0 * (pow(10.0, (m_max * i / (n_mels + 1)) / 2595.0) - 1.0);
+        for (int k = 0; k < nfreq; ++k) {
+            const double f = fmax * k / (nfreq - 1);
+            for (int m = 0; m < n_mels; ++m) {
+                const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
+                const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
+                const double v = down < up ? down : up;
+                mel[(size_t)m * kp + k] = (float)(v > 0.0 ? v : 0.0);
+            }
+        }
+        HIPCHK(hipMemcpy(ctx->fb_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->fb_mel, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice));
+        ctx->fb_rate = sample_rate;
+        ctx->fb_nfft = n_fft;
+    }
+    if ((rc = grow(ctx, &ctx->fb_pad, &ctx->fb_pad_cap, (size_t)B * pstride))) return rc;
+    if ((rc = grow(ctx, &ctx->fb_spec, &ctx->fb_spec_cap, (size_t)M * n2p))) return rc;
+    if ((rc = grow(ctx, &ctx->fb_pow, &ctx->fb_pow_cap, (size_t)M * kp))) return rc;
+    hipLaunchKernelGGL(reflect_pad, dim3(grid_for((long long)B * pstride)), dim3(256), 0, s, wave_dev, ctx->fb_pad, B, n_samples, n_fft / 2, pstride);
+    LAUNCHCHK("reflect_pad");
+    // windowed DFT: implicit frames (row t of stream b starts at b*pstride + t*hop), K = n_fft
+    GemmP g1 = plain_gemm(ctx->fb_pad, hop, ctx->fb_dft, n_fft, nullptr, ctx->fb_spec, n2p, (int)M, n2p, n_fft);
+    g1.a_n1 = T; g1.a_n2 = T; g1.a_s0 = pstride; g1.a_s1 = 0; g1.a_s2 = hop;
+    if ((rc = launch_gemm(ctx, s, 0, &g1, 1))) return rc;
+    hipLaunchKernelGGL(power_spectrum, dim3(grid_for(M * kp)), dim3(256), 0, s, ctx->fb_spec, ctx->fb_pow, M, nfreq, kp, n2p);
+    LAUNCHCHK("power_spectrum");
+    GemmP g2 = plain_gemm(ctx->fb_pow, kp, ctx->fb_mel, kp, nullptr, out_dev, n_mels, (int)M, n_mels, kp, EPI_DB);
+    if ((rc = launch_gemm(ctx, s, 0, &g2, 1))) return rc;
+    if (frames_out) *frames_out = T;
     return RNNT_OK;
 }
 

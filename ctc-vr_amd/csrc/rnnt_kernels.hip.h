@@ -40,7 +40,8 @@ enum {
     EPI_GLU = 5,       // interleaved (a,gate) columns -> C[:, n/2] = a * sigmoid(gate)
     EPI_LSTM = 6,      // interleaved (i,f,g,o) columns + input table row -> h', c'
     EPI_TANH_ADD = 7,  // C = tanh(acc + bias + X[gather(m)][n])   (joint: enc_proj[t_b] + pred_proj)
-    EPI_ARGMAX = 8     // no store: per-row argmax of (acc + bias) over all columns into key[m] (greedy decode)
+    EPI_ARGMAX = 8,    // no store: per-row argmax of (acc + bias) over all columns into key[m] (greedy decode)
+    EPI_DB = 9         // C = 10 * log10(max(acc + bias, 1e-10))   (AmplitudeToDB, power spectrogram)
 };
 
 struct GemmP {
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(64 * WK) void gemm32(GemmBatch gb) {
             else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
             else if (epi == EPI_SCALE) v = v * p.alpha;
             else if (epi == EPI_RESID) v = p.R[crow + n] + p.alpha * v;
+            else if (epi == EPI_DB) v = 10.0f * log10f(fmaxf(v, 1e-10f));
             else if (epi == EPI_TANH_ADD) {
                 const int bi = m / p.x_n;
                 const int fr = p.I ? p.I[bi] : (m % p.x_n);
@@ -609,6 +611,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
         else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
         else if (epi == EPI_SCALE) v = v * p.alpha;
         else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
+        else if (epi == EPI_DB) v = 10.0f * log10f(fmaxf(v, 1e-10f));
         else if (epi == EPI_TANH_ADD) {
             const int bi = fastdiv(m, p.x_n, p.x_n_magic, p.x_n_shift);
             const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
@@ -846,6 +849,7 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
                 else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
                 else if (epi == EPI_SCALE) v = v * p.alpha;
                 else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
+                else if (epi == EPI_DB) v = 10.0f * log10f(fmaxf(v, 1e-10f));
                 else if (epi == EPI_TANH_ADD) {
                     const int bi = fastdiv(m, p.x_n, p.x_n_magic, p.x_n_shift);
                     const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
@@ -1772,6 +1776,42 @@ __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
     if (tid == 0) {
         p.sel[b] = 0; p.tok[b] = tok; p.fidx[b] = fidx; p.nsym[b] = nsym; p.count[b] = count;
         atomicAdd(p.ctrl + 2, evals);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature front-end (data/dataloader.py:15-41, torchaudio MelSpectrogram(center=True, pad_mode="reflect") + AmplitudeToDB):
+// reflect_pad makes the n_fft/2-padded signal, the windowed DFT is a GEMM over implicit frames (row stride = hop) against
+// interleaved (w cos, -w sin) rows, power_spectrum squares and adds the pairs, the mel projection is a second GEMM with
+// the dB conversion as its epilogue.
+// ------------------------------------------------------------------------------------------------
+__global__ void reflect_pad(const float* __restrict__ x, float* __restrict__ y, int B, int n, int pad, long long ystride) {
+    const long long total = (long long)B * ystride;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(id / ystride);
+        const int i = (int)(id - (long long)b * ystride);
+        float v = 0.f;
+        if (i < n + 2 * pad) {
+            int j = i - pad;
+            if (j < 0) j = -j;                      // reflect without repeating the edge sample
+            if (j >= n) j = 2 * (n - 1) - j;
+            v = x[(long long)b * n + j];
+        }
+        y[id] = v;
+    }
+}
+// spec [M][2*nfp] interleaved (re, im) -> pw [M][kp]: re^2 + im^2 for k < nfreq, 0 for the padding columns
+__global__ void power_spectrum(const float* __restrict__ spec, float* __restrict__ pw, long long M, int nfreq, int kp, int ldspec) {
+    const long long total = M * kp;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long long)gridDim.x * blockDim.x) {
+        const long long m = id / kp;
+        const int k = (int)(id - m * kp);
+        float v = 0.f;
+        if (k < nfreq) {
+            const float2 c = *reinterpret_cast<const float2*>(spec + m * ldspec + 2 * k);
+            v = c.x * c.x + c.y * c.y;
+        }
+        pw[id] = v;
     }
 }
 

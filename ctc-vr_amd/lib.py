@@ -38,6 +38,7 @@ SIGNATURES = {
     "rnnt_joint": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rnnt_encoder_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_ctc_argmax": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
+    "rnnt_fbank": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_get_att_cache": (c_i32, [c_vp, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_get_cnn_cache": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "rnnt_get_predictor_state": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32p, c_vp]),
@@ -216,6 +217,12 @@ class RnntEngine:
         self._chk(self.lib.rnnt_ctc_argmax(self.ctx, fbank_ptr, _np_ptr(lens), B, T, _np_ptr(ids), ctypes.byref(t), stream), "rnnt_ctc_argmax")
         self.n_streams = 0
         return ids
+
+    def fbank(self, wave_ptr, B, n_samples, sample_rate, out_ptr, n_fft=1024, stream=None):
+        """Device feature front-end (data/dataloader.py:15-41): wave [B, n_samples] -> out [B, 1 + n_samples // 512, 80]."""
+        t = c_i32(0)
+        self._chk(self.lib.rnnt_fbank(self.ctx, wave_ptr, B, n_samples, sample_rate, n_fft, out_ptr, ctypes.byref(t), stream), "rnnt_fbank")
+        return t.value
 
     # ---- state read-back ----------------------------------------------------------------------
     def att_cache(self, b=0, stream=None):

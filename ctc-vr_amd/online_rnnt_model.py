@@ -134,6 +134,12 @@ class OnlineRNNTModel:
         self._loaded = True
 
     # ---- streaming state (model/online_rnnt_model.py:138-164) ----------------------------------------
+    def extract_audio_features(self, waveform, sample_rate, n_fft=1024):
+        """Device version of data/dataloader.py:extract_audio_features: waveform [n] or [B, n] -> [.., 1 + n // 512, 80] dB
+        mel features on this model's GPU (ctc_vr_amd.features)."""
+        from .features import extract_audio_features
+        return extract_audio_features(self._engine, waveform, sample_rate, n_fft=n_fft)
+
     def reset_streaming_cache(self, device=None):
         self._require_loaded()
         self._engine.reset(1, _stream_ptr())

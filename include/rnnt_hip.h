@@ -161,6 +161,13 @@ int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens
 int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T,
                     int32_t* ids_host, int32_t* frames_out, void* stream);
 
+/* Feature front-end on the device: replaces extract_audio_features (data/dataloader.py:15-41) =
+ * torchaudio MelSpectrogram(sample_rate, n_fft, n_mels=80, hop_length=512, hamming window, power 2, centred reflect
+ * padding, HTK mel scale) + AmplitudeToDB().  wave_dev [B, n_samples] mono float32 on the device ->
+ * out_dev [B, 1 + n_samples/512, 80] (the layout rnnt_encoder_chunk takes).  Independent of the model weights. */
+int rnnt_fbank(rnnt_ctx* ctx, const float* wave_dev, int32_t B, int32_t n_samples, int32_t sample_rate, int32_t n_fft,
+               float* out_dev, int32_t* frames_out, void* stream);
+
 /* -- state read-back in the reference's layouts (parity tests, facade attributes) -------------- */
 /* streaming_att_cache of one stream: [12, 4, len, 128] (K = [...,:64], V = [...,64:],
  * wenet/transformer/encoder.py:284); *len_out = cached frames.  dst_host may be NULL to query len. */

@@ -330,6 +330,34 @@ def test_ctc_greedy_search_against_oracle(models, np_state_dict):
     assert got == want and len(got[0]) > 0
 
 
+def test_fbank_frontend_against_oracle(models):
+    """rnnt_fbank (windowed DFT + mel projection as f32 MFMA GEMMs, dB epilogue) vs the NumPy float64 restatement of
+    torchaudio's MelSpectrogram + AmplitudeToDB.  PARITY UNPINNED against the reference itself (no torchaudio here, no
+    fixture in the reference); tolerance 2e-3 dB on bins above -60 dB (f32 DFT by GEMM vs f64 FFT), 0.05 dB below."""
+    from oracle import fbank_oracle as F
+    from ctc_vr_amd.features import extract_audio_features
+    eng = models(0, 16)._engine
+    rng = np.random.default_rng(5)
+    for rate, n, B in ((16000, 16000, 3), (48000, 30001, 2), (16000, 700, 1)):
+        t = np.arange(n) / rate
+        w = 0.1 * rng.standard_normal((B, n)) + 0.5 * np.sin(2 * np.pi * 440.0 * t)[None, :]
+        w[0, n // 2:] = 0.0                                                        # digital silence: the -100 dB floor
+        got = extract_audio_features(eng, torch.from_numpy(w.astype(np.float32)), rate).cpu().numpy()
+        assert got.shape == (B, 1 + n // 512, 80)
+        for b in range(B):
+            want = F.extract_audio_features(w[b].astype(np.float32), rate)
+            hi = want > -60.0
+            assert np.max(np.abs(got[b][hi] - want[hi])) < 2e-3, (rate, n, b)
+            lo = ~hi
+            if lo.any():
+                assert np.max(np.abs(got[b][lo] - want[lo])) < 0.05 or np.all(got[b][lo] < -59.9), (rate, n, b)
+    one = extract_audio_features(eng, torch.from_numpy(w[0].astype(np.float32)), rate).cpu().numpy()   # 1-D input form
+    assert np.array_equal(one, got[0])
+    assert models(0, 16).extract_audio_features(torch.from_numpy(w[0].astype(np.float32)), rate).shape == got[0].shape
+    with pytest.raises(Exception):
+        extract_audio_features(eng, torch.zeros(400), 16000)                       # <= n_fft/2 samples: reflect padding impossible
+
+
 def test_rtf_harness(models):
     """per-chunk RTF statistics with online_rnnt_delay.py's definition."""
     from ctc_vr_amd.online_rnnt_delay import evaluate_rtf
