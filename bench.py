@@ -294,6 +294,43 @@ def main():
         roofline["launches_timed"] = int(site_launches)
         roofline["share_of_step"] = round(site_ms * 1e-3 / elapsed, 4)
 
+    # The same kernel with nothing else on the device: in the timed region the subsampling stream runs UNDER the encoder
+    # stages and next to the resident decoder, which is good for the step time and bad for this one kernel's duration.
+    # A second context with the overlaps switched off times it alone (same inputs, same launches, outside the timed region).
+    roofline_isolated = None
+    if roofline is not None and world == 1 and args.mode == "pipelined":
+        saved = {k: os.environ.get(k) for k in ("RNNT_WF_SUB_ASYNC", "RNNT_WF_GROUPS")}
+        os.environ["RNNT_WF_SUB_ASYNC"] = "0"
+        os.environ["RNNT_WF_GROUPS"] = "1"
+        sb2 = StreamingBatch(sd_np, B, max_chunk_frames=max(b - a for a, b in plan), max_cache_frames=enc_frames + 8,
+                             max_enc_frames=enc_frames + 8, max_tokens=enc_frames * 10 + 16, device=local_rank)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        plan_args = ([a for a, _ in plan], [b - a for a, b in plan], [4 * i for i in range(len(plan))])
+        cs = torch.cuda.current_stream().cuda_stream
+
+        def enc_only():
+            sb2.reset()
+            sb2.engine.encoder_chunks(x.data_ptr(), args.frames, plan_args[0], plan_args[1], plan_args[2], plan_args[2], cs, greedy=False)
+        enc_only()
+        torch.cuda.synchronize()
+        sb2.engine.profile_begin(TAGS[args.site])
+        for _ in range(2):
+            enc_only()
+        torch.cuda.synchronize()
+        iso_ms, iso_n = sb2.engine.profile_end()
+        if iso_n > 0:
+            hbm = roofline["bound"] == "hbm"
+            ach = (by if hbm else fl) * 2 / (iso_ms * 1e-3) / (1e9 if hbm else 1e12)
+            peak = PEAK_HBM_GBS if hbm else PEAK_F32_MFMA_TFLOPS
+            roofline_isolated = {"achieved": round(ach, 2), "peak": peak, "unit": roofline["unit"], "frac": round(ach / peak, 4),
+                                 "avg_launch_us": round(iso_ms * 1e3 / iso_n, 2), "launches_timed": int(iso_n),
+                                 "note": "same kernel and launches, encoder only, subsampling stream and layer-group streams off (nothing else on the device)"}
+        del sb2
+
     per_chunk_extra = None
     if args.also_per_chunk and args.mode != "per_chunk" and world == 1:
         sb.decode_script(x, args.chunk, per_chunk_decode=True)
@@ -346,6 +383,7 @@ def main():
         "greedy_steps_per_step": int(gsteps),
         "weight_broadcast_ms": round(bcast_ms, 3),
         "roofline": roofline,
+        "roofline_isolated": roofline_isolated,
         "cpu_baseline": cpu,
         "per_chunk_api": per_chunk_extra,
     }

@@ -419,7 +419,10 @@ int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T
         memset(&gb, 0, sizeof(gb));
         gb.g[0] = g;
         if ((rc = prepare_gemm(ctx, gb.g[0]))) return rc;
-        launch_gemm_ns<2, 2>(s, gb, g.M, g.N, 1);
+        if (conv2_lds == 24) launch_gemm_ns<2, 4>(s, gb, g.M, g.N, 1);
+        else if (conv2_lds == 42) launch_gemm_ns<4, 2>(s, gb, g.M, g.N, 1);
+        else if (conv2_lds == 44) launch_gemm_ns<4, 4>(s, gb, g.M, g.N, 1);
+        else launch_gemm_ns<2, 2>(s, gb, g.M, g.N, 1);
         LAUNCHCHK("gemm_ns");
     } else if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;
     // Linear(4864 -> 256) * sqrt(256); y2 is [VB*t', f*256 + c] (weight columns permuted to match)
