@@ -583,8 +583,8 @@ int greedy_drain(rnnt_ctx* ctx, hipStream_t s, int n_frames, int done_steps) {
 
 // Persistent greedy decoder: one resident workgroup per 2 streams decodes every frame up to n_total, waiting on
 // dec_ctrl[0] (frames_ready).  The control block must have been initialised on a stream this one is ordered after.
-int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total) {
-    if (ctx->use_coop && ctx->n_streams <= 64) {
+int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total, int n_steps_override = 0, const int* nlim = nullptr) {
+    if (ctx->use_coop && ctx->n_streams <= 64 && !nlim && !n_steps_override) {
         // cooperative decoder: 64 resident workgroups, weights stationary in LDS, 3 grid barriers per evaluation
         CoopP c;
         memset(&c, 0, sizeof(c));
@@ -609,11 +609,14 @@ int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total) {
     d.fstride_f = (long long)ctx->fstride * D; d.bstride = (long long)ctx->cfg.max_streams * D;
     d.B = ctx->n_streams; d.vocab = ctx->cfg.vocab_size; d.blank = ctx->cfg.blank_id; d.n_steps = ctx->cfg.n_steps;
     d.max_tokens = ctx->cfg.max_tokens; d.n_total = n_total;
+    if (n_steps_override > 0) d.n_steps = n_steps_override;
+    d.nlim = nlim;
     d.timeout_ticks = 500000000ll;   // 5 s of the 100 MHz real-time counter: every wait in the kernel is bounded
     static const int dth = getenv("RNNT_DEC_THREADS") ? atoi(getenv("RNNT_DEC_THREADS")) : 512;   // 1 stream / 512 threads: no spills,
     static const int spw = getenv("RNNT_DEC_SPW") ? atoi(getenv("RNNT_DEC_SPW")) : 1;             // best of the measured variants
     const int B = ctx->n_streams;
-    static const int kf = getenv("RNNT_DEC_KF") ? atoi(getenv("RNNT_DEC_KF")) : 4;   // frames per vocabulary pass (0: old kernel)
+    static const int kf_env = getenv("RNNT_DEC_KF") ? atoi(getenv("RNNT_DEC_KF")) : 4;   // frames per vocabulary pass (0: old kernel)
+    const int kf = (nlim || n_steps_override) && kf_env == 0 ? 4 : kf_env;                   // only greedy_stream knows the offline options
     if (kf == 1) hipLaunchKernelGGL(greedy_stream<1>, dim3(B), dim3(512), 0, s, d);
     else if (kf == 2) hipLaunchKernelGGL(greedy_stream<2>, dim3(B), dim3(512), 0, s, d);
     else if (kf == 4) hipLaunchKernelGGL(greedy_stream<4>, dim3(B), dim3(512), 0, s, d);
@@ -1640,6 +1643,41 @@ int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_h
     HIPCHK(hipMemcpyAsync(ids_host, ids, rows * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (frames_out) *frames_out = tq;
+    return RNNT_OK;
+}
+
+// Offline greedy search: model/component/transducer.py:22-70 `basic_greedy_search` as reached from
+// OnlineRNNTModel.forward (online_rnnt_model.py:234-235,268) for a non-streaming model: full-context encoder, then per
+// utterance a greedy RNN-T loop over its own valid frames with at most n_steps symbols per frame (default 64 there), zero
+// predictor state, first token = blank.  (The reference reads `model.blank`, an attribute OnlineRNNTModel does not have;
+// the blank id of the context is used.)  Unlike the streaming loop there is no forced frame advance after n_steps symbols
+// other than leaving the inner loop -- which is the same thing -- so the resident decoder is reused unchanged with
+// per-stream frame counts.  counts_host [B], tokens_host [B][max_tokens].
+int rnnt_greedy_search_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T, int32_t n_steps,
+                            int32_t* counts_host, int32_t* tokens_host, void* stream) {
+    if (!ctx || !counts_host) return fail(ctx, RNNT_ERR_ARG, "rnnt_greedy_search_full: null argument");
+    if (n_steps < 1) return fail(ctx, RNNT_ERR_ARG, "rnnt_greedy_search_full: n_steps %d", n_steps);
+    hipStream_t s = (hipStream_t)stream;
+    const int tq = sub_len(T);
+    const size_t rows = (size_t)B * tq;
+    if (rows * D > ctx->scratch_floats) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_greedy_search_full: B=%d T=%d exceeds the context scratch", B, T);
+    if (tq > ctx->fcap) return fail(ctx, RNNT_ERR_SHAPE, "rnnt_greedy_search_full: %d encoder frames exceed max_enc_frames %d", tq, ctx->fcap);
+    int rc, fo = 0;
+    if ((rc = rnnt_streams_reset(ctx, B, stream))) return rc;                                   // zero predictor state, token = blank
+    if ((rc = rnnt_encoder_full(ctx, fbank_dev, lens_host, B, T, ctx->scratch, &fo, stream))) return rc;   // also fills ctx->klen (valid frames)
+    ctx->n_streams = B;
+    {   // joint.enc_ffn of every frame, [B*tq, 256] -> enc_proj [B][fstride][256]
+        GemmP g = plain_gemm(ctx->scratch, D, ctx->wenc, D, ctx->benc, ctx->encp, D, (int)rows, D, D);
+        g.c_n = tq; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = 0; g.c_mod = BIG; g.c_s1 = D;
+        if ((rc = launch_gemm(ctx, s, 0, &g, 1, TAG_ENC_PROJ))) return rc;
+    }
+    if ((rc = init_decoder_ctrl(ctx, s, tq))) return rc;
+    if ((rc = launch_persistent_decoder(ctx, s, tq, n_steps, ctx->klen))) return rc;
+    if ((rc = finish_persistent_decoder(ctx, s))) return rc;
+    ctx->n_streams = 0;                                                                        // streaming state is not meaningful afterwards
+    HIPCHK(hipMemcpyAsync(counts_host, ctx->count, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (tokens_host) HIPCHK(hipMemcpyAsync(tokens_host, ctx->tokens, (size_t)B * ctx->cfg.max_tokens * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return RNNT_OK;
 }
 

@@ -1419,6 +1419,7 @@ struct DecP {
     long long bstride;    // floats between the two state buffers
     int B, vocab, blank, n_steps, max_tokens, n_total;
     long long timeout_ticks;   // s_memrealtime ticks (100 MHz)
+    const int* nlim;           // optional per-stream frame count (offline search over padded batches); null = n_total for all
 };
 
 template <int SPW, int NTH, int U = 2, typename Epi>
@@ -1653,11 +1654,12 @@ __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
         if (tid < RNNT_D) { hs[0][tid] = ldg1(p.h + off + tid); cs[tid] = ldg1(p.c + off + tid); }
     }
     int tok = ldgi(p.tok + b), fidx = ldgi(p.fidx + b), nsym = ldgi(p.nsym + b), count = ldgi(p.count + b);   // uniform
+    const int n_total = p.nlim ? min(p.n_total, ldgi(p.nlim + b)) : p.n_total;
     int evals = 0, seen_ready = 0;
     bool dirty = true;
     const float* encp = p.encp + (long long)b * p.fstride_f;
     __syncthreads();
-    while (fidx < p.n_total) {
+    while (fidx < n_total) {
         // ---- frames available to this stream (bounded wait) ------------------------------------------------------------
         if (tid == 0) {
             int nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1683,7 +1685,7 @@ __global__ __launch_bounds__(512) void greedy_stream(DecP p) {
         if (s_ctl[0]) break;
         // frames evaluated together: right after a symbol only the current frame (more symbols are likely on it and the
         // single-frame pass is cheaper), otherwise up to KF
-        const int kf = dirty ? 1 : min(KF, min(s_ctl[1], p.n_total) - fidx);
+        const int kf = dirty ? 1 : min(KF, min(s_ctl[1], n_total) - fidx);
         if (dirty) {
             // ---- predictor step: gates = E[tok] + W_hh h; candidate (h', c'); pp = W_c h' + b_c ---------------------------
             dec_matvec<1, NTH, UL>(p.whh, 4 * RNNT_D, hs, [&](int n, const float* acc) {

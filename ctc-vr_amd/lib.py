@@ -39,6 +39,7 @@ SIGNATURES = {
     "rnnt_encoder_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_ctc_argmax": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_fbank": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32p, c_vp]),
+    "rnnt_greedy_search_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rnnt_get_att_cache": (c_i32, [c_vp, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_get_cnn_cache": (c_i32, [c_vp, c_i32, c_vp, c_vp]),
     "rnnt_get_predictor_state": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32p, c_vp]),
@@ -217,6 +218,18 @@ class RnntEngine:
         self._chk(self.lib.rnnt_ctc_argmax(self.ctx, fbank_ptr, _np_ptr(lens), B, T, _np_ptr(ids), ctypes.byref(t), stream), "rnnt_ctc_argmax")
         self.n_streams = 0
         return ids
+
+    def greedy_search_full(self, fbank_ptr, lens, B, T, n_steps=64, stream=None):
+        """Offline greedy search over the full-context encoder (model/component/transducer.py:22-70) -> list of token lists."""
+        lens = np.ascontiguousarray(lens, np.int32)
+        counts = np.zeros(B, np.int32)
+        toks = np.zeros((B, self.cfg.max_tokens), np.int32)
+        self._chk(self.lib.rnnt_greedy_search_full(self.ctx, fbank_ptr, _np_ptr(lens), B, T, n_steps, _np_ptr(counts), _np_ptr(toks), stream),
+                  "rnnt_greedy_search_full")
+        self.n_streams = 0
+        if counts.max(initial=0) > self.cfg.max_tokens:
+            raise RnntError("token buffer overflow: raise max_tokens")
+        return [toks[b, :counts[b]].tolist() for b in range(B)]
 
     def fbank(self, wave_ptr, B, n_samples, sample_rate, out_ptr, n_fft=1024, stream=None):
         """Device feature front-end (data/dataloader.py:15-41): wave [B, n_samples] -> out [B, 1 + n_samples // 512, 80]."""

@@ -326,9 +326,26 @@ class OnlineRNNTModel:
         return hyps
 
     def forward(self, audios, audio_lens, texts=None, text_lens=None):
-        if not self.streaming or texts is not None:
-            raise NotImplementedError("training / offline forward is outside the accelerated path (SURVEY.md §8a: a4,a5 only)")
-        return self.streaming_inference(audios, audio_lens)
+        """Inference branches of the reference's forward (model/online_rnnt_model.py:224-272): a streaming model goes to
+        streaming_inference (:271-272); a non-streaming model runs the full-context encoder and basic_greedy_search
+        (:234-235,268; model/component/transducer.py:22-70, n_steps=64) for the whole batch.  The training branch
+        (texts given: joint lattice + rnnt_loss) is outside the accelerated path."""
+        if texts is not None:
+            raise NotImplementedError("training forward (loss) is outside the accelerated path (SURVEY.md §8a)")
+        if self.streaming:
+            return self.streaming_inference(audios, audio_lens)
+        return self.greedy_search_full(audios, audio_lens), None, None
+
+    def greedy_search_full(self, audios, audio_lens, n_steps: int = 64):
+        """basic_greedy_search over the deterministic full-context encoder; audios [B,T,80] with B <= max_streams,
+        T <= max_chunk_frames, ((T-3)//2+1-3)//2+1 <= max_enc_frames.  Invalidates the streaming state."""
+        self._require_loaded()
+        B, T = audios.size(0), audios.size(1)
+        x = audios.to(self.device, torch.float32).contiguous()
+        lens = audio_lens.detach().cpu().numpy().astype(np.int32)
+        hyps = self._engine.greedy_search_full(x.data_ptr(), lens, B, T, n_steps, _stream_ptr())
+        self._chunks_done = None
+        return hyps
 
     __call__ = forward
 

@@ -161,6 +161,13 @@ int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens
 int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T,
                     int32_t* ids_host, int32_t* frames_out, void* stream);
 
+/* Offline greedy search: basic_greedy_search (model/component/transducer.py:22-70) behind
+ * OnlineRNNTModel.forward(audios, audio_lens) of a non-streaming model (model/online_rnnt_model.py:234-235,268):
+ * full-context encoder + per-utterance greedy loop over its valid frames, <= n_steps symbols per frame (reference
+ * default 64).  counts_host [B]; tokens_host [B, max_tokens] (may be NULL).  Streaming state is clobbered. */
+int rnnt_greedy_search_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T,
+                            int32_t n_steps, int32_t* counts_host, int32_t* tokens_host, void* stream);
+
 /* Feature front-end on the device: replaces extract_audio_features (data/dataloader.py:15-41) =
  * torchaudio MelSpectrogram(sample_rate, n_fft, n_mels=80, hop_length=512, hamming window, power 2, centred reflect
  * padding, HTK mel scale) + AmplitudeToDB().  wave_dev [B, n_samples] mono float32 on the device ->

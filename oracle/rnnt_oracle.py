@@ -208,6 +208,32 @@ def encoder_full(sd: SD, xs: Tensor, xs_lens: Tensor) -> Tuple[Tensor, Tensor]:
     return _ln(sd, "encoder.after_norm", x), masks
 
 
+def basic_greedy_search_full(sd, x, lens, blank=5, n_steps=64):
+    """model/component/transducer.py:22-70 as reached from OnlineRNNTModel.forward (:234-235,268) for a non-streaming
+    model: full-context encoder, then per utterance the greedy loop over its valid frames -- fresh zero predictor state,
+    previous token = blank, up to n_steps symbols per frame, state/token advance only on non-blank, leave the inner loop
+    on blank.  x [B,T,80], lens [B] -> list of token lists."""
+    y, mask = encoder_full(sd, x, lens)
+    out_lens = mask.squeeze(1).sum(1)
+    hyps = []
+    for b in range(x.shape[0]):
+        hyp = []
+        h = torch.zeros(1, 1, 256)
+        c = torch.zeros(1, 1, 256)
+        tok = blank
+        for t in range(int(out_lens[b])):
+            enc_t = y[b:b + 1, t:t + 1, :]
+            for _ in range(n_steps):
+                pred, (h2, c2) = predictor_step(sd, torch.tensor([[tok]]), (h, c))
+                k = int(torch.argmax(joint(sd, enc_t, pred).reshape(-1)))
+                if k == blank:
+                    break
+                hyp.append(k)
+                tok, h, c = k, h2, c2
+        hyps.append(hyp)
+    return hyps
+
+
 def ctc_greedy_search_full(sd: SD, xs: Tensor, xs_lens: Tensor, blank: int) -> List[List[int]]:
     """OnlineRNNTModel.ctc_greedy_search (model/online_rnnt_model.py:647-671) on the deterministic full-context
     encoder (the reference's own call uses a random dynamic chunk mask in eval, SURVEY.md §0.8, so only this variant

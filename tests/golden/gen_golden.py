@@ -285,10 +285,35 @@ def gen_cer():
     save("cer_cases.npz", hyp=hyp, ref=refs, lens=lens, result=res)
 
 
+@torch.no_grad()
+def gen_offline():
+    """Offline greedy search: the reference's basic_greedy_search (model/component/transducer.py:22-70) on the
+    deterministic full-context encoder output (decoding_chunk_size=-1).  The function reads `model.blank`, which
+    OnlineRNNTModel does not define (it has blank_id), so it is given a three-attribute view of the model."""
+    import types
+    from model.component.transducer import basic_greedy_search
+    for seed in (0, 1):
+        net = build(seed, 16)
+        view = types.SimpleNamespace(predictor=net.predictor, joint=net.joint, blank=net.blank_id)
+        x = torch.from_numpy(T.synth_fbank(3, 240, seed=77 + seed))
+        lens = torch.tensor([240, 171, 96])
+        y, m = net.encoder(x, lens, decoding_chunk_size=-1)
+        out_lens = m.squeeze(1).sum(1)
+        out = {}
+        for n_steps in (64, 3):
+            flat, cnt = pack_tokens(basic_greedy_search(view, y, out_lens, n_steps=n_steps))
+            out[f"tokens_n{n_steps}"] = flat
+            out[f"counts_n{n_steps}"] = cnt
+        save(f"offline_greedy_seed{seed}.npz", lens=lens.numpy(), out_lens=out_lens.numpy(), **out)
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
     if len(sys.argv) > 1 and sys.argv[1] == "cer":
         gen_cer()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "offline":
+        gen_offline()
         sys.exit(0)
     inp = gen_inputs()
     gen_modules(0, inp)
@@ -296,3 +321,4 @@ if __name__ == "__main__":
     gen_streams(inp)
     gen_full(inp)
     gen_cer()
+    gen_offline()

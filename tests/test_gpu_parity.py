@@ -358,6 +358,25 @@ def test_fbank_frontend_against_oracle(models):
         extract_audio_features(eng, torch.zeros(400), 16000)                       # <= n_fft/2 samples: reflect padding impossible
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_offline_greedy_search_matches_reference(seed, np_state_dict):
+    """rnnt_greedy_search_full / OnlineRNNTModel.forward of a non-streaming model vs the reference's basic_greedy_search
+    on its full-context encoder (golden, ragged batch of 3, n_steps 64 and 3): tokens exact."""
+    from ctc_vr_amd.online_rnnt_model import OnlineRNNTModel
+    g = load_golden(f"offline_greedy_seed{seed}.npz")
+    m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=T.VOCAB, blank_id=T.BLANK, streaming=False, predictor_dropout=0,
+                        max_streams=3, max_chunk_frames=256, max_enc_frames=64, max_tokens=4096)
+    m.load_state_dict(np_state_dict(seed))
+    x = torch.from_numpy(T.synth_fbank(3, 240, seed=77 + seed))
+    lens = torch.from_numpy(g["lens"])
+    for n_steps in (64, 3):
+        hyps = m.greedy_search_full(x, lens, n_steps=n_steps)
+        assert [len(h) for h in hyps] == g[f"counts_n{n_steps}"].tolist(), n_steps
+        assert [t for h in hyps for t in h] == g[f"tokens_n{n_steps}"].tolist(), n_steps
+    hyps, a, b = m(x, lens)                                   # forward(): n_steps = 64
+    assert a is None and b is None and [len(h) for h in hyps] == g["counts_n64"].tolist()
+
+
 def test_rtf_harness(models):
     """per-chunk RTF statistics with online_rnnt_delay.py's definition."""
     from ctc_vr_amd.online_rnnt_delay import evaluate_rtf

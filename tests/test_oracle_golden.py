@@ -168,3 +168,17 @@ def test_encoder_full_context(sds):
     x6 = ex_inputs()["ex6"]
     y6, _ = O.encoder_full(sd, x6, torch.tensor([x6.shape[1]]))
     assert maxdiff(y6, g6["out"]) < 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_offline_greedy_search(seed, np_state_dict):
+    """basic_greedy_search (model/component/transducer.py:22-70) on the full-context encoder, n_steps 64 and 3."""
+    g = load_golden(f"offline_greedy_seed{seed}.npz")
+    sd = O.to_torch_sd(np_state_dict(seed))
+    x = torch.from_numpy(T.synth_fbank(3, 240, seed=77 + seed))
+    lens = torch.from_numpy(g["lens"])
+    for n_steps in (64, 3):
+        hyps = O.basic_greedy_search_full(sd, x, lens, blank=T.BLANK, n_steps=n_steps)
+        cnt = g[f"counts_n{n_steps}"]
+        assert [len(h) for h in hyps] == cnt.tolist()
+        assert [t for h in hyps for t in h] == g[f"tokens_n{n_steps}"].tolist()
