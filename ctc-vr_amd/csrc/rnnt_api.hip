@@ -65,6 +65,7 @@ struct rnnt_ctx {
     int* dec_ctrl = nullptr;   // persistent decoder control block: [0] frames_ready, [1] error, [2] evaluations, [3..6] cooperative decoder
     int use_persistent = 1;
     int attn_stream = 1;       // RNNT_ATTN_STREAM=0: LDS-tiled attention kernel for every chunk
+    int fuse_after_norm = 1;   // RNNT_FUSE_AFTER_NORM=0: keep after_norm as its own launch in the pipelined greedy path
     int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
     float* coop_z = nullptr; int* coop_st2 = nullptr; unsigned long long* coop_key2 = nullptr;
@@ -105,7 +106,7 @@ struct rnnt_ctx {
     std::vector<DecGraph> dec_graphs;          // K greedy steps captured once per (n_streams, K)
     bool capturing = false;
     int use_graphs = 1;
-    std::vector<hipEvent_t> wf_ev, wf_evd;
+    std::vector<hipEvent_t> wf_ev;
     // optional per-kernel-site timing with HIP events on the launch stream (bench.py roofline leg)
     int prof_tag = -1;
     std::vector<hipEvent_t> prof_ev;
@@ -441,7 +442,8 @@ void launch_gemm16_tab(hipStream_t s, const GemmP* tab, int n, int maxM, int max
 int launch_gemm_tab(rnnt_ctx* ctx, hipStream_t s, const GemmP* tab_dev, int n, int maxM, int N, int K, int tag) {
     ProfScope prof(ctx, s, tag);
     static const int ns_mode = getenv("RNNT_GEMM_NS") ? atoi(getenv("RNNT_GEMM_NS")) : 1;
-    if (ns_mode && n >= 6 && K % 32 == 0) {   // enough groups: no split-K, epilogue from registers
+    static const int ns_min = getenv("RNNT_NS_MIN_GROUPS") ? atoi(getenv("RNNT_NS_MIN_GROUPS")) : 2;   // pipeline fill/drain stages have few pairs
+    if (ns_mode && n >= ns_min && K % 32 == 0) {   // enough groups: no split-K, epilogue from registers
         // tile choice from tools/microbench2.hip (12 groups x 192 rows): the kernel is occupancy/latency-bound, so the
         // narrow shapes want many small workgroups; only K = 1024 profits from 64-deep K blocks (half the barriers)
         // XCDs per descriptor (see gemm_ns_tab): the largest split that keeps the groups balanced
@@ -612,26 +614,13 @@ int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total, int n_s
     if (n_steps_override > 0) d.n_steps = n_steps_override;
     d.nlim = nlim;
     d.timeout_ticks = 500000000ll;   // 5 s of the 100 MHz real-time counter: every wait in the kernel is bounded
-    static const int dth = getenv("RNNT_DEC_THREADS") ? atoi(getenv("RNNT_DEC_THREADS")) : 512;   // 1 stream / 512 threads: no spills,
-    static const int spw = getenv("RNNT_DEC_SPW") ? atoi(getenv("RNNT_DEC_SPW")) : 1;             // best of the measured variants
     const int B = ctx->n_streams;
-    static const int kf_env = getenv("RNNT_DEC_KF") ? atoi(getenv("RNNT_DEC_KF")) : 4;   // frames per vocabulary pass (0: old kernel)
-    const int kf = (nlim || n_steps_override) && kf_env == 0 ? 4 : kf_env;                   // only greedy_stream knows the offline options
+    static const int kf = getenv("RNNT_DEC_KF") ? atoi(getenv("RNNT_DEC_KF")) : 4;   // frames per vocabulary pass
     if (kf == 1) hipLaunchKernelGGL(greedy_stream<1>, dim3(B), dim3(512), 0, s, d);
     else if (kf == 2) hipLaunchKernelGGL(greedy_stream<2>, dim3(B), dim3(512), 0, s, d);
-    else if (kf == 4) hipLaunchKernelGGL(greedy_stream<4>, dim3(B), dim3(512), 0, s, d);
     else if (kf == 8) hipLaunchKernelGGL(greedy_stream<8>, dim3(B), dim3(512), 0, s, d);
-    else if (spw == 1) {
-        if (dth == 512) hipLaunchKernelGGL((greedy_persistent<1, 512>), dim3(B), dim3(512), 0, s, d);
-        else hipLaunchKernelGGL((greedy_persistent<1, 1024>), dim3(B), dim3(1024), 0, s, d);
-    } else if (spw == 4) {
-        hipLaunchKernelGGL((greedy_persistent<4, 1024>), dim3((B + 3) / 4), dim3(1024), 0, s, d);
-    } else {
-        if (dth == 256) hipLaunchKernelGGL((greedy_persistent<2, 256>), dim3((B + 1) / 2), dim3(256), 0, s, d);
-        else if (dth == 512) hipLaunchKernelGGL((greedy_persistent<2, 512>), dim3((B + 1) / 2), dim3(512), 0, s, d);
-        else hipLaunchKernelGGL((greedy_persistent<2, 1024>), dim3((B + 1) / 2), dim3(1024), 0, s, d);
-    }
-    LAUNCHCHK("greedy_persistent");
+    else hipLaunchKernelGGL(greedy_stream<4>, dim3(B), dim3(512), 0, s, d);
+    LAUNCHCHK("greedy_stream");
     return RNNT_OK;
 }
 
@@ -719,6 +708,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     if (const char* pe = getenv("RNNT_PERSISTENT")) ctx->use_persistent = (pe[0] == '0') ? 0 : 1;
     if (const char* ce = getenv("RNNT_COOP")) ctx->use_coop = (ce[0] == '0') ? 0 : 1;
     if (const char* ae = getenv("RNNT_ATTN_STREAM")) ctx->attn_stream = (ae[0] == '0') ? 0 : 1;
+    if (const char* fe = getenv("RNNT_FUSE_AFTER_NORM")) ctx->fuse_after_norm = (fe[0] == '0') ? 0 : 1;
     if (const char* ge = getenv("RNNT_WF_GROUPS")) { const int g = atoi(ge); ctx->wf_groups = g < 1 ? 1 : (g > 4 ? 4 : g); }
     if (const char* se = getenv("RNNT_WF_SUB_ASYNC")) ctx->wf_sub_async = (se[0] == '0') ? 0 : 1;
     const int B = cfg->max_streams;
@@ -782,7 +772,6 @@ void rnnt_destroy(rnnt_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->wf_ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ctx->wf_evd) (void)hipEventDestroy(e);
     if (ctx->dec_stream) (void)hipStreamDestroy(ctx->dec_stream);
     for (auto& g : ctx->dec_graphs) (void)hipGraphExecDestroy(g.exec);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
@@ -1343,9 +1332,17 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         const int c = st - (L - 1);   // chunk whose last block just ran
         if (c < 0) continue;
         // (c) after_norm straight into the frame buffer + joint.enc_ffn projection of the chunk's frames
-        if ((rc = launch_ln(ctx, sl, LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
-                                         (long long)ctx->fstride * D, (long long)D}))) return rc;
-        {
+        if (greedy && resident && ctx->fuse_after_norm) {
+            // greedy decode reads only enc_proj: after_norm goes into the projection's LayerNorm prologue and the
+            // normalised frames are not materialised (rnnt_get_enc_frames is not defined after such a call)
+            const int F = ci[c].tq;
+            GemmP g = plain_gemm(ctx->wf_x + ci[c].xoff * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * F, D, D);
+            g.ln_g = ctx->after_g; g.ln_b = ctx->after_b;
+            g.c_n = F; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ci[c].fpos; g.c_mod = BIG; g.c_s1 = D;
+            if ((rc = launch_gemm(ctx, sl, 0, &g, 1, TAG_ENC_PROJ))) return rc;
+        } else {
+            if ((rc = launch_ln(ctx, sl, LnP{ctx->wf_x + ci[c].xoff * D, ctx->after_g, ctx->after_b, ctx->encbuf, B * ci[c].tq, ci[c].tq, ci[c].fpos,
+                                             (long long)ctx->fstride * D, (long long)D}))) return rc;
             const int F = ci[c].tq;
             GemmP g = plain_gemm(ctx->encbuf + (size_t)ci[c].fpos * D, D, ctx->wenc, D, ctx->benc, ctx->encp, D, B * F, D, D);
             g.a_n1 = F; g.a_n2 = F; g.a_s0 = (long long)ctx->fstride * D; g.a_s1 = 0; g.a_s2 = D;

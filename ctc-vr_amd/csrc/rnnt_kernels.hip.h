@@ -1381,8 +1381,8 @@ __global__ __launch_bounds__(64) void greedy_decide(int B, int blank, int n_step
 }
 
 // ------------------------------------------------------------------------------------------------
-// greedy_persistent<SPW>: the whole greedy decode of an utterance batch as ONE resident kernel.
-// One workgroup owns SPW streams for the whole call and runs their RNN-T greedy state machine
+// Resident greedy decoder (kernel greedy_stream below): the whole greedy decode of an utterance batch as ONE kernel.
+// One workgroup owns one stream for the whole call and runs their RNN-T greedy state machine
 // (_decode_chunk_streaming_logic, online_rnnt_model.py:193-220) without any exchange with other workgroups:
 //   LSTM cell      gates = E[tok] + W_hh h      (predictor.py:200-204; gate rows interleaved i,f,g,o per unit)
 //   joint          z = tanh(enc_proj[t] + W_c h' + b_c), W_c = W_pf W_pr folded (joint.py:54-66)
@@ -1461,168 +1461,6 @@ __device__ __forceinline__ void dec_matvec(const float* __restrict__ W, int nrow
             if (l == 0 && n < nrows) epi(n, acc);
         }
     }
-}
-
-template <int SPW, int NTH>
-__global__ __launch_bounds__(NTH) void greedy_persistent(DecP p) {
-    __shared__ __attribute__((aligned(16))) float hs[SPW][RNNT_D], cs[SPW][RNNT_D], h2[SPW][RNNT_D], c2[SPW][RNNT_D], zs[SPW][RNNT_D];
-    __shared__ __attribute__((aligned(16))) float gates[SPW][4 * RNNT_D];
-    __shared__ float redv[NTH / 16][SPW];
-    __shared__ int redi[NTH / 16][SPW];
-    __shared__ int s_tok[SPW], s_fidx[SPW], s_nsym[SPW], s_count[SPW], s_valid[SPW], s_active[SPW], s_ctl[4];
-    const int tid = threadIdx.x;
-    const int b0 = blockIdx.x * SPW;
-    if (b0 >= p.B) return;
-    // ---- load the streams' state (committed LSTM buffer, token, frame cursor) -------------------------------------
-    for (int e = tid; e < SPW * RNNT_D; e += NTH) {
-        const int s = e >> 8, j = e & 255, b = b0 + s;
-        float hv = 0.f, cv = 0.f;
-        if (b < p.B) {
-            const long long off = (long long)(ldgi(p.sel + b) & 1) * p.bstride + (long long)b * RNNT_D + j;
-            hv = ldg1(p.h + off);
-            cv = ldg1(p.c + off);
-        }
-        hs[s][j] = hv;
-        cs[s][j] = cv;
-    }
-    if (tid < SPW) {
-        const int b = b0 + tid;
-        const bool v = b < p.B;
-        s_valid[tid] = v ? 1 : 0;
-        s_tok[tid] = v ? ldgi(p.tok + b) : p.blank;
-        s_fidx[tid] = v ? ldgi(p.fidx + b) : p.n_total;
-        s_nsym[tid] = v ? ldgi(p.nsym + b) : 0;
-        s_count[tid] = v ? ldgi(p.count + b) : 0;
-    }
-    if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0; }
-    __syncthreads();
-    int evals = 0;
-    int seen_ready = 0;
-    while (true) {
-        // ---- wait until one of my streams has a frame to decode (or everything is decoded) -----------------------
-        if (tid == 0) {
-            int done = 1, any = 0;
-            int nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-            while (true) {
-                done = 1; any = 0;
-                for (int s = 0; s < SPW; ++s) {
-                    const int f = s_fidx[s];
-                    if (s_valid[s] && f < p.n_total) done = 0;
-                    const int act = (s_valid[s] && f < nf) ? 1 : 0;
-                    s_active[s] = act;
-                    any |= act;
-                }
-                if (done || any) break;
-                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {   // bounded wait: give up loudly
-                    __hip_atomic_store(p.ctrl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    done = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-                nf = __hip_atomic_load(p.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (nf > seen_ready) {   // new frames became visible: ONE acquire so that nobody reads stale enc_proj lines
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                seen_ready = nf;
-            }
-            s_ctl[0] = done;
-        }
-        __syncthreads();
-        if (s_ctl[0]) break;
-        // ---- LSTM gates: gates[s][n] = E[tok_s][n] + W_hh[n] . h_s -------------------------------------------------
-        dec_matvec<SPW, NTH>(p.whh, 4 * RNNT_D, hs, [&](int n, const float* acc) {
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) gates[s][n] = acc[s] + ldg1(p.egate + (long long)s_tok[s] * (4 * RNNT_D) + n);
-        });
-        __syncthreads();
-        for (int e = tid; e < SPW * RNNT_D; e += NTH) {
-            const int s = e >> 8, j = e & 255;
-            const float4 gt = *reinterpret_cast<const float4*>(&gates[s][4 * j]);
-            const float cc = sigmoidf_(gt.y) * cs[s][j] + sigmoidf_(gt.x) * tanhf(gt.z);
-            c2[s][j] = cc;
-            h2[s][j] = sigmoidf_(gt.w) * tanhf(cc);
-        }
-        __syncthreads();
-        // ---- joint: z = tanh(enc_proj[b][t] + W_c h' + b_c) ---------------------------------------------------------
-        dec_matvec<SPW, NTH>(p.wjc, RNNT_D, h2, [&](int n, const float* acc) {
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) {
-                float e = 0.f;
-                if (s_active[s]) e = ldg1(p.encp + (long long)(b0 + s) * p.fstride_f + (long long)s_fidx[s] * RNNT_D + n);
-                zs[s][n] = tanhf(acc[s] + ldg1(p.bjc + n) + e);
-            }
-        });
-        __syncthreads();
-        // ---- vocabulary projection + argmax (rows ascend per lane group: strict > keeps the first maximum) -------
-        float bv[SPW];
-        int bi[SPW];
-#pragma unroll
-        for (int s = 0; s < SPW; ++s) { bv[s] = -INFINITY; bi[s] = 0x7fffffff; }
-        dec_matvec<SPW, NTH>(p.wout, p.vocab, zs, [&](int n, const float* acc) {
-            const float bo = ldg1(p.bout + n);
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) {
-                const float v = acc[s] + bo;
-                if (v > bv[s]) { bv[s] = v; bi[s] = n; }
-            }
-        });
-        if ((tid & 15) == 0) {
-#pragma unroll
-            for (int s = 0; s < SPW; ++s) { redv[tid >> 4][s] = bv[s]; redi[tid >> 4][s] = bi[s]; }
-        }
-        __syncthreads();
-        // ---- decision ---------------------------------------------------------------------------------------------------
-        if (tid < SPW && s_active[tid]) {
-            const int s = tid, b = b0 + s;
-            float best = -INFINITY;
-            int k = 0x7fffffff;
-            for (int g = 0; g < NTH / 16; ++g) {
-                const float v = redv[g][s];
-                const int ix = redi[g][s];
-                if (v > best || (v == best && ix < k)) { best = v; k = ix; }
-            }
-            if (k == p.blank) {
-                s_fidx[s] += 1;
-                s_nsym[s] = 0;
-                s_active[s] = 0;           // nothing to commit
-            } else {
-                const int cnt = s_count[s];
-                if (cnt < p.max_tokens) p.tokens[(long long)b * p.max_tokens + cnt] = k;
-                s_count[s] = cnt + 1;
-                s_tok[s] = k;
-                const int ns = s_nsym[s] + 1;
-                if (ns >= p.n_steps) { s_nsym[s] = 0; s_fidx[s] += 1; } else { s_nsym[s] = ns; }
-                s_active[s] = 2;           // commit flag
-            }
-        } else if (tid < SPW) {
-            s_active[tid] = 0;
-        }
-        __syncthreads();
-        for (int e = tid; e < SPW * RNNT_D; e += NTH) {   // commit (h', c') of the streams that emitted a symbol
-            const int s = e >> 8, j = e & 255;
-            if (s_active[s] == 2) { hs[s][j] = h2[s][j]; cs[s][j] = c2[s][j]; }
-        }
-        ++evals;
-        __syncthreads();
-    }
-    // ---- write the state back (buffer 0 becomes the committed one) ----------------------------------------------------
-    for (int e = tid; e < SPW * RNNT_D; e += NTH) {
-        const int s = e >> 8, j = e & 255, b = b0 + s;
-        if (b < p.B) {
-            stg1(p.h + (long long)b * RNNT_D + j, hs[s][j]);
-            stg1(p.c + (long long)b * RNNT_D + j, cs[s][j]);
-        }
-    }
-    if (tid < SPW && b0 + tid < p.B) {
-        const int b = b0 + tid;
-        p.sel[b] = 0;
-        p.tok[b] = s_tok[tid];
-        p.fidx[b] = s_fidx[tid];
-        p.nsym[b] = s_nsym[tid];
-        p.count[b] = s_count[tid];
-    }
-    if (tid == 0) atomicAdd(p.ctrl + 2, evals);
 }
 
 // ------------------------------------------------------------------------------------------------
