@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <array>
 #include <vector>
 
 namespace {
@@ -96,6 +97,7 @@ struct rnnt_ctx {
     hipStream_t grp_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // layer groups 1.. of the wavefront (group 0 = caller's stream)
     hipStream_t sub_stream = nullptr;          // subsampling slabs
     int wf_groups = 2, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4), RNNT_WF_SUB_ASYNC
+    int wf_merge = 2;                          // RNNT_WF_MERGE (1..WF_MERGE_MAX): chunks of one layer per wavefront stage
     std::vector<hipEvent_t> ev_pool;
     // feature front-end (rnnt_fbank): DFT / mel matrices for (fb_rate, fb_nfft) and grow-only work buffers
     float *fb_dft = nullptr, *fb_mel = nullptr, *fb_pad = nullptr, *fb_spec = nullptr, *fb_pow = nullptr;
@@ -165,6 +167,7 @@ int dmalloc(rnnt_ctx* ctx, T** p, size_t n) {
     return RNNT_OK;
 }
 
+constexpr int WF_MERGE_MAX = 4;   // chunks of one layer per wavefront stage (rnnt_encoder_chunks), upper bound
 inline int sub_len(int T) { return ((T - 3) / 2 + 1 - 3) / 2 + 1; }   // subsampling.py:188-193
 inline int sub1_len(int T) { return (T - 3) / 2 + 1; }
 
@@ -710,11 +713,12 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     if (const char* ae = getenv("RNNT_ATTN_STREAM")) ctx->attn_stream = (ae[0] == '0') ? 0 : 1;
     if (const char* fe = getenv("RNNT_FUSE_AFTER_NORM")) ctx->fuse_after_norm = (fe[0] == '0') ? 0 : 1;
     if (const char* ge = getenv("RNNT_WF_GROUPS")) { const int g = atoi(ge); ctx->wf_groups = g < 1 ? 1 : (g > 4 ? 4 : g); }
+    if (const char* me = getenv("RNNT_WF_MERGE")) { const int m = atoi(me); ctx->wf_merge = m < 1 ? 1 : (m > WF_MERGE_MAX ? WF_MERGE_MAX : m); }
     if (const char* se = getenv("RNNT_WF_SUB_ASYNC")) ctx->wf_sub_async = (se[0] == '0') ? 0 : 1;
     const int B = cfg->max_streams;
     ctx->tmax = sub_len(cfg->max_chunk_frames);
     ctx->t1max = sub1_len(cfg->max_chunk_frames);
-    ctx->cap = RNNT_LORDER + ctx->tmax;
+    ctx->cap = RNNT_LORDER + WF_MERGE_MAX * ctx->tmax;   // several chunks of one layer may be in flight in one wavefront stage
     ctx->tcap = cfg->max_cache_frames;
     ctx->fcap = cfg->max_enc_frames;
     ctx->fstride = ctx->fcap + 1;   // +1 row: finished streams read one frame past the end
@@ -1130,10 +1134,10 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         if (ctx->wf_slab < 1) ctx->wf_slab = 1;
         if (ctx->wf_slab > 16) ctx->wf_slab = 16;
         if ((rc = dmalloc(ctx, &ctx->wf_x, Bm * ctx->fcap * D))) return rc;
-        if ((rc = dmalloc(ctx, &ctx->wf_h, (size_t)L * Mmax * FF))) return rc;
-        if ((rc = dmalloc(ctx, &ctx->wf_q, (size_t)L * Mmax * D))) return rc;
-        if ((rc = dmalloc(ctx, &ctx->wf_a, (size_t)L * Mmax * D))) return rc;
-        if ((rc = dmalloc(ctx, &ctx->wf_d, (size_t)L * Mmax * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_h, (size_t)L * WF_MERGE_MAX * Mmax * FF))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_q, (size_t)L * WF_MERGE_MAX * Mmax * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_a, (size_t)L * WF_MERGE_MAX * Mmax * D))) return rc;
+        if ((rc = dmalloc(ctx, &ctx->wf_d, (size_t)L * WF_MERGE_MAX * Mmax * D))) return rc;
         if ((rc = dmalloc(ctx, &ctx->wf_y1, (size_t)ctx->wf_slab * Bm * ctx->t1max * RNNT_F1 * D))) return rc;
         if ((rc = dmalloc(ctx, &ctx->wf_y2, (size_t)ctx->wf_slab * Mmax * RNNT_FSUB * D))) return rc;
     }
@@ -1166,7 +1170,8 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     hipEvent_t e_in;
     if ((rc = new_event(&e_in))) return rc;
     HIPCHK(hipEventRecord(e_in, s));                       // everything the caller enqueued before this call
-    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(gs[g], e_in, 0));
+    for (int g = 0; g < G; ++g)
+        if (gs[g] != s) HIPCHK(hipStreamWaitEvent(gs[g], e_in, 0));
     if (ss != s) HIPCHK(hipStreamWaitEvent(ss, e_in, 0));
     // ---- (a) subsampling, runs of equal-length chunks in slabs ------------------------------------------
     HIPCHK(hipMemcpyAsync(ctx->wf_starts, chunk_start, C * sizeof(int), hipMemcpyHostToDevice, ss));
@@ -1188,22 +1193,46 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     std::vector<GemmP> gt; std::vector<AttnP> at; std::vector<DwP> dt; std::vector<LnP> lt;
     std::vector<Launch> seq;
     gt.reserve((size_t)C * L * 12); at.reserve((size_t)C * L); dt.reserve((size_t)C * L); lt.reserve((size_t)C * (L + 1));
+    // Stage of pair (chunk c, layer l) = c / KM + l: KM consecutive chunks of a layer share a stage.  Everything but
+    // attention and the depthwise conv is per-frame, and those two only need the SAME layer's K/V rows / ring rows of the
+    // earlier chunks, which the stage's QKV / pointwise_conv1 launch has written before the attention / depthwise launch
+    // starts.  Fewer, fatter stages: the fixed cost of a launch (ramp, prologue, epilogue) is paid per 2 chunks.
+    // A chunk joins its predecessor's stage only if the K/V rows it appends lie behind everything the predecessor reads or
+    // writes (the reference re-bases the cache at row 0 after the first chunk, whose K/V are dropped: chunk 1 would overwrite
+    // chunk 0's rows inside one launch).
+    const int KM = ctx->wf_merge;
+    std::vector<int> sc_first;                               // first chunk of every super-chunk (+ C)
+    for (int c = 0, cnt = 0; c < C; ++c) {
+        const bool behind = c > 0 && ci[c].kv_row0 + ci[c].T2 - ci[c].tq >= ci[c - 1].kv_row0 + ci[c - 1].T2;
+        if (c == 0 || cnt == KM || !behind) { sc_first.push_back(c); cnt = 0; }
+        ++cnt;
+    }
+    const int NSC = (int)sc_first.size();                    // super-chunks
+    sc_first.push_back(C);
+    const int NS = NSC + L - 1;                              // stages
     std::vector<LayerDescs> cur;
-    for (int st = 0; st < C + L - 1; ++st) {
+    std::vector<std::array<int, 13>> lstart((size_t)NS);     // per stage: first pair index of every layer (+ total)
+    for (int st = 0; st < NS; ++st) {
         cur.clear();
         int maxM = 0, maxtq = 0, maxT2 = 0;
         for (int l = 0; l < L; ++l) {
-            const int c = st - l;
-            if (c < 0 || c >= C) continue;
-            LayerDescs d;
-            LayerBufs bf{ctx->wf_x + ci[c].xoff * D, ctx->wf_h + (size_t)l * Mmax * FF, ctx->wf_q + (size_t)l * Mmax * D,
-                         ctx->wf_a + (size_t)l * Mmax * D, ctx->wf_d + (size_t)l * Mmax * D};
-            if ((rc = build_layer(ctx, l, B, ci[c].tq, ci[c].T2, ci[c].kv_row0, ci[c].pos_start, ci[c].ring_pos, nullptr, bf, d))) return rc;
-            cur.push_back(d);
-            if (B * ci[c].tq > maxM) maxM = B * ci[c].tq;
-            if (ci[c].tq > maxtq) maxtq = ci[c].tq;
-            if (ci[c].T2 > maxT2) maxT2 = ci[c].T2;
+            lstart[st][l] = (int)cur.size();
+            const int sc = st - l;
+            if (sc < 0 || sc >= NSC) continue;
+            for (int c = sc_first[sc]; c < sc_first[sc + 1]; ++c) {
+                const int j = c - sc_first[sc];
+                LayerDescs d;
+                const size_t slot = (size_t)l * WF_MERGE_MAX + j;
+                LayerBufs bf{ctx->wf_x + ci[c].xoff * D, ctx->wf_h + slot * Mmax * FF, ctx->wf_q + slot * Mmax * D,
+                             ctx->wf_a + slot * Mmax * D, ctx->wf_d + slot * Mmax * D};
+                if ((rc = build_layer(ctx, l, B, ci[c].tq, ci[c].T2, ci[c].kv_row0, ci[c].pos_start, ci[c].ring_pos, nullptr, bf, d))) return rc;
+                cur.push_back(d);
+                if (B * ci[c].tq > maxM) maxM = B * ci[c].tq;
+                if (ci[c].tq > maxtq) maxtq = ci[c].tq;
+                if (ci[c].T2 > maxT2) maxT2 = ci[c].T2;
+            }
         }
+        lstart[st][L] = (int)cur.size();
         const int n = (int)cur.size();
         auto add_g = [&](int type, GemmP LayerDescs::*f) -> int {
             seq.push_back({type, (int)gt.size(), n, maxM, 0});
@@ -1239,11 +1268,12 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     static const int gN[8] = {FF, D, D, D, 2 * D, D, FF, D};
     static const int gK[8] = {D, FF, D, D, D, D, D, FF};
     static const int gTag[8] = {TAG_FFN1, TAG_FFN2, TAG_QKV, TAG_ATTN_OUT, TAG_PW1, TAG_PW2, TAG_FFN1, TAG_FFN2};
-    if (G > 1) {                                            // the other groups read the tables copied on s
+    {                                                       // the other streams read the tables copied on s
         hipEvent_t e_tab;
         if ((rc = new_event(&e_tab))) return rc;
         HIPCHK(hipEventRecord(e_tab, s));
-        for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(gs[g], e_tab, 0));
+        for (int g = 0; g < G; ++g)
+            if (gs[g] != s) HIPCHK(hipStreamWaitEvent(gs[g], e_tab, 0));
     }
     hipStream_t sl = gs[G - 1];                             // the stream the last layer runs on
     // decode stream + events (greedy != 0): chunk c's frames are decodable once its layer-11 stage, after_norm and
@@ -1265,8 +1295,8 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         ctx->pinned[8] = 0;
         if (ctx->use_persistent && ctx->overlap_ok < 0) {   // the resident decoder must not block ANY stream the encoder uses
             if ((rc = probe_overlap(ctx, s, s2))) return rc;
-            for (int g = 1; g < G && ctx->overlap_ok == 1; ++g)
-                if ((rc = probe_overlap(ctx, gs[g], s2))) return rc;
+            for (int g = 0; g < G && ctx->overlap_ok == 1; ++g)
+                if (gs[g] != s && (rc = probe_overlap(ctx, gs[g], s2))) return rc;
             if (ss != s && ctx->overlap_ok == 1 && (rc = probe_overlap(ctx, ss, s2))) return rc;
         }
         resident = ctx->use_persistent && ctx->overlap_ok == 1;
@@ -1282,18 +1312,19 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     double t_enc = 0, t_dec = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tl = now();
-    std::vector<hipEvent_t> grp_ev((size_t)G * (C + L), nullptr);   // [g][st]: group g finished its part of stage st
-    for (int st = 0; st < C + L - 1; ++st) {
-        const int lmin = st - C + 1 > 0 ? st - C + 1 : 0, lmax = st < L - 1 ? st : L - 1;   // layers with a chunk in this stage
+    std::vector<hipEvent_t> grp_ev((size_t)G * (NS + 1), nullptr);   // [g][st]: group g finished its part of stage st
+    for (int st = 0; st < NS; ++st) {
+        const std::array<int, 13>& ls = lstart[st];
         for (int g = 0; g < G; ++g) {
             const int lo = g * L / G, hi = (g + 1) * L / G;                                  // layers [lo, hi) of this group
-            const int l0 = lo > lmin ? lo : lmin, l1 = (hi - 1) < lmax ? (hi - 1) : lmax;
-            if (l0 > l1) continue;
-            const int p0 = l0 - lmin, pn = l1 - l0 + 1;                                      // pairs [p0, p0 + pn) of the stage
+            const int p0 = ls[lo], pn = ls[hi] - ls[lo];                                     // pairs [p0, p0 + pn) of the stage
+            if (pn <= 0) continue;
             hipStream_t x = gs[g];
-            if (l0 == 0 && slab_ev[st]) HIPCHK(hipStreamWaitEvent(x, slab_ev[st], 0));      // layer 0 of chunk st: its slab is subsampled
-            if (g > 0 && l0 == lo && st > 0 && grp_ev[(size_t)(g - 1) * (C + L) + st - 1])
-                HIPCHK(hipStreamWaitEvent(x, grp_ev[(size_t)(g - 1) * (C + L) + st - 1], 0));
+            if (lo == 0 && ls[1] > ls[0])                                                    // layer 0: its chunks' slabs are subsampled
+                for (int c = sc_first[st]; c < sc_first[st + 1]; ++c)
+                    if (slab_ev[c]) HIPCHK(hipStreamWaitEvent(x, slab_ev[c], 0));
+            if (g > 0 && ls[lo + 1] > ls[lo] && st > 0 && grp_ev[(size_t)(g - 1) * (NS + 1) + st - 1])
+                HIPCHK(hipStreamWaitEvent(x, grp_ev[(size_t)(g - 1) * (NS + 1) + st - 1], 0));
             for (int j = 0; j < 11; ++j) {
                 const Launch& q = seq[(size_t)st * 11 + j];
                 if (q.type < 8) {
@@ -1322,15 +1353,17 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
                     LAUNCHCHK("layer_norm_tab");
                 }
             }
-            if (g < G - 1 && l1 == hi - 1) {                // the next group's first layer reads this group's last layer
+            if (g < G - 1 && ls[hi] > ls[hi - 1]) {         // the next group's first layer reads this group's last layer
                 hipEvent_t e;
                 if ((rc = new_event(&e))) return rc;
                 HIPCHK(hipEventRecord(e, x));
-                grp_ev[(size_t)g * (C + L) + st] = e;
+                grp_ev[(size_t)g * (NS + 1) + st] = e;
             }
         }
-        const int c = st - (L - 1);   // chunk whose last block just ran
-        if (c < 0) continue;
+        const int scl = st - (L - 1);   // super-chunk whose last block just ran
+        if (scl < 0) continue;
+        int stage_frames = 0, c_last = -1;
+        for (int c = sc_first[scl]; c < sc_first[scl + 1]; ++c) {
         // (c) after_norm straight into the frame buffer + joint.enc_ffn projection of the chunk's frames
         if (greedy && resident && ctx->fuse_after_norm) {
             // greedy decode reads only enc_proj: after_norm goes into the projection's LayerNorm prologue and the
@@ -1349,18 +1382,22 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
             g.c_n = F; g.c_s0 = (long long)ctx->fstride * D; g.c_r0 = ci[c].fpos; g.c_mod = BIG; g.c_s1 = D;
             if ((rc = launch_gemm(ctx, sl, 0, &g, 1, TAG_ENC_PROJ))) return rc;
         }
+            stage_frames += ci[c].tq;
+            c_last = c;
+        }
         if (timing) { double t = now(); t_enc += t - tl; tl = t; }
-        if (greedy && resident) {   // the resident decoder sees the chunk's frames as soon as this lands
-            hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, sl, ctx->dec_ctrl, ci[c].fpos + ci[c].tq);
+        if (c_last < 0) continue;
+        if (greedy && resident) {   // the resident decoder sees the stage's frames as soon as this lands
+            hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, sl, ctx->dec_ctrl, ci[c_last].fpos + ci[c_last].tq);
             LAUNCHCHK("publish_frames");
         } else if (greedy) {
-            HIPCHK(hipEventRecord(ctx->wf_ev[c], sl));
-            HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c], 0));
-            // launched decode path: this chunk's frames + a little slack per chunk, in hipGraph-captured batches
+            HIPCHK(hipEventRecord(ctx->wf_ev[c_last], sl));
+            HIPCHK(hipStreamWaitEvent(s2, ctx->wf_ev[c_last], 0));
+            // launched decode path: this stage's frames + a little slack, in hipGraph-captured batches
             static const int slack = getenv("RNNT_DEC_SLACK") ? atoi(getenv("RNNT_DEC_SLACK")) : 8;
-            int budget = ci[c].tq + slack;
+            int budget = stage_frames + slack;
             budget = (budget + 3) / 4 * 4;   // few distinct graph sizes
-            if ((rc = greedy_steps(ctx, s2, budget, ci[c].fpos + ci[c].tq))) return rc;
+            if ((rc = greedy_steps(ctx, s2, budget, ci[c_last].fpos + ci[c_last].tq))) return rc;
             dec_steps += budget;
             if (timing) { double t = now(); t_dec += t - tl; tl = t; }
         }
@@ -1369,7 +1406,8 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     if (frames_out) *frames_out = fb - fb0;
     ctx->cache_len = cache_len; ctx->kv_start = kv_start; ctx->conv_pos = conv_pos; ctx->frames_buffered = fb;
     // ---- join: the caller's stream continues after every internal stream ---------------------------------------------
-    for (int g = 1; g < G; ++g) {
+    for (int g = 0; g < G; ++g) {
+        if (gs[g] == s) continue;
         hipEvent_t e;
         if ((rc = new_event(&e))) return rc;
         HIPCHK(hipEventRecord(e, gs[g]));

@@ -52,13 +52,22 @@ void run(const char* name, int G, int M, int N, int K, bool ln) {
     CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(tab));
 }
 int main(int argc, char** argv) {
-    run<1, 2, 32, 1>("ffn1 <1,2,32> PD1 +LN", 12, 192, 1024, 256, true);
-    run<1, 2, 32, 2>("ffn1 <1,2,32> PD2 +LN", 12, 192, 1024, 256, true);
-    run<1, 2, 32, 4>("ffn1 <1,2,32> PD4 +LN", 12, 192, 1024, 256, true);
-    run<1, 2, 32, 2>("ffn1 <1,2,32> PD2 noLN", 12, 192, 1024, 256, false);
-    run<2, 2, 32, 2>("ffn1 <2,2,32> PD2 +LN", 12, 192, 1024, 256, true);
-    run<1, 1, 64, 2>("ffn2 <1,1,64> PD2", 12, 192, 256, 1024, false);
-    run<1, 1, 32, 2>("qkv <1,1,32> PD2 +LN", 36, 192, 256, 256, true);
+    // 6 pairs per launch = one layer group of the two-stream wavefront
+    run<1, 2, 32, 2>("ffn1 6p <1,2,32> +LN", 6, 192, 1024, 256, true);
+    run<2, 2, 32, 2>("ffn1 6p <2,2,32> +LN", 6, 192, 1024, 256, true);
+    run<2, 4, 32, 2>("ffn1 6p <2,4,32> +LN", 6, 192, 1024, 256, true);
+    run<1, 4, 32, 2>("ffn1 6p <1,4,32> +LN", 6, 192, 1024, 256, true);
+    run<1, 1, 64, 2>("ffn2 6p <1,1,64>", 6, 192, 256, 1024, false);
+    run<1, 2, 64, 2>("ffn2 6p <1,2,64>", 6, 192, 256, 1024, false);
+    run<2, 2, 32, 2>("ffn2 6p <2,2,32>", 6, 192, 256, 1024, false);
+    run<2, 1, 64, 2>("ffn2 6p <2,1,64>", 6, 192, 256, 1024, false);
+    run<1, 1, 32, 2>("qkv 18p <1,1,32> +LN", 18, 192, 256, 256, true);
+    run<1, 2, 32, 2>("qkv 18p <1,2,32> +LN", 18, 192, 256, 256, true);
+    run<2, 2, 32, 2>("qkv 18p <2,2,32> +LN", 18, 192, 256, 256, true);
+    run<1, 1, 32, 2>("out 6p <1,1,32>", 6, 192, 256, 256, false);
+    run<1, 2, 32, 2>("out 6p <1,2,32>", 6, 192, 256, 256, false);
+    run<1, 2, 32, 2>("pw1 6p <1,2,32> +LN", 6, 192, 512, 256, true);
+    run<1, 1, 32, 2>("pw1 6p <1,1,32> +LN", 6, 192, 512, 256, true);
     printf("done\n");
     return 0;
 }
