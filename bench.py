@@ -198,6 +198,9 @@ def main():
                                                                 "B=1 ops are tiny, more threads are slower)")
     ap.add_argument("--also-per-chunk", type=int, default=1, help="also time the per-chunk API mode (reported as extra fields)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--blank-bias", type=float, default=12.0,
+                    help="bias on the blank logit of the seeded weights: sets the greedy symbol rate (SURVEY.md §8d asks for 0.3-1 symbols per "
+                         "encoder frame; 12.0 gives 0.75, the fixtures' 11.0 gives 1.40, 14.0 gives 0.17)")
     ap.add_argument("--workload", default="greedy", choices=["greedy", "beam", "full_context", "joint_lattice"],
                     help="greedy = BASELINE configs[1] (default); beam = configs[2] (beam 4, per-chunk); full_context = configs[4]")
     args = ap.parse_args()
@@ -215,7 +218,7 @@ def main():
 
     # ---- weights: generated on rank 0, ONE RCCL broadcast of the packed blob over xGMI --------------------
     import ctc_vr_amd.dist as D
-    sd0 = T.make_state_dict(0) if rank == 0 else None
+    sd0 = T.make_state_dict(0, blank_bias=args.blank_bias) if rank == 0 else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sd_np = D.broadcast_state_dict(sd0, src=0, device=dev)
@@ -377,7 +380,7 @@ def main():
         "config": {"workload": f"configs[1]: batch={B}/GPU synthetic {args.frames / 100:.0f} s 80-dim fbank, streaming chunk={args.chunk} "
                                f"(online_rnnt_decode.py semantics), greedy decode, {args.mode} token return",
                    "streams_per_gpu": B, "frames_per_stream": args.frames, "chunk_frames": args.chunk, "chunks": len(plan),
-                   "encoder_frames_per_stream": enc_frames, "symbols_per_encoder_frame": round(syms, 3), "weights": "seeded synthetic (seed 0)",
+                   "encoder_frames_per_stream": enc_frames, "symbols_per_encoder_frame": round(syms, 3), "weights": f"seeded synthetic (seed 0, blank_bias {args.blank_bias})",
                    "parallelism": f"streams sharded x{world}, no data-path collective"},
         "kernel_launches_per_step": int(launches),
         "greedy_steps_per_step": int(gsteps),
