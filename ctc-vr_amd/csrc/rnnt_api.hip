@@ -224,13 +224,13 @@ static int prefetch_depth() {   // K blocks in flight per workgroup (register ri
     static const int pd = getenv("RNNT_GEMM_PD") ? atoi(getenv("RNNT_GEMM_PD")) : 2;
     return pd;
 }
-template <int MT, int NT, bool ATANH = false>
+template <int MT, int NT, bool ATANH = false, bool ANT = false>
 void launch_gemm_ns(hipStream_t s, const GemmBatch& gb, int maxM, int maxN, int ng) {
     const int ntn = (maxN + 32 * NT - 1) / (32 * NT), ntm = (maxM + 32 * MT - 1) / (32 * MT);
     dim3 grid(((ntm + 7) / 8) * 8 * ntn, 1, ng);
     switch (prefetch_depth()) {
-        case 1: hipLaunchKernelGGL((gemm_ns<MT, NT, 32, 1, ATANH>), grid, dim3(256), 0, s, gb, ntn, ntm); break;
-        default: hipLaunchKernelGGL((gemm_ns<MT, NT, 32, 2, ATANH>), grid, dim3(256), 0, s, gb, ntn, ntm); break;
+        case 1: hipLaunchKernelGGL((gemm_ns<MT, NT, 32, 1, ATANH, ANT>), grid, dim3(256), 0, s, gb, ntn, ntm); break;
+        default: hipLaunchKernelGGL((gemm_ns<MT, NT, 32, 2, ATANH, ANT>), grid, dim3(256), 0, s, gb, ntn, ntm); break;
     }
 }
 
@@ -423,9 +423,7 @@ int run_subsample(rnnt_ctx* ctx, hipStream_t s, const float* fbank, int B, int T
         memset(&gb, 0, sizeof(gb));
         gb.g[0] = g;
         if ((rc = prepare_gemm(ctx, gb.g[0]))) return rc;
-        if (conv2_lds == 24) launch_gemm_ns<2, 4>(s, gb, g.M, g.N, 1);
-        else if (conv2_lds == 42) launch_gemm_ns<4, 2>(s, gb, g.M, g.N, 1);
-        else if (conv2_lds == 44) launch_gemm_ns<4, 4>(s, gb, g.M, g.N, 1);
+        if (conv2_lds == 2 && nc > 1) launch_gemm_ns<2, 2, false, true>(s, gb, g.M, g.N, 1);   // experiment: non-temporal A
         else launch_gemm_ns<2, 2>(s, gb, g.M, g.N, 1);
         LAUNCHCHK("gemm_ns");
     } else if ((rc = launch_gemm(ctx, s, 8, &g, 1, TAG_CONV2))) return rc;

@@ -114,6 +114,7 @@ __device__ __forceinline__ float4 ldg4_nt(const float* p) {
 __device__ __forceinline__ float ldg1(const float* p) { return *(const RNNT_GAS float*)p; }
 __device__ __forceinline__ int ldgi(const int* p) { return *(const RNNT_GAS int*)p; }
 __device__ __forceinline__ void stg1(float* p, float v) { *(RNNT_GAS float*)p = v; }
+__device__ __forceinline__ void stg1_nt(float* p, float v) { __builtin_nontemporal_store(v, (RNNT_GAS float*)p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *(RNNT_GAS f32x4g*)p = (f32x4g){v.x, v.y, v.z, v.w}; }
 #else   // host pass of the single-source compile: never executed
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -121,6 +122,7 @@ __device__ __forceinline__ float4 ldg4_nt(const float* p) { return *reinterpret_
 __device__ __forceinline__ float ldg1(const float* p) { return *p; }
 __device__ __forceinline__ int ldgi(const int* p) { return *p; }
 __device__ __forceinline__ void stg1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stg1_nt(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #endif
 
@@ -648,7 +650,7 @@ __device__ long long ns_trace[8192 * 8];
 #else
 #define NS_STAMP(k_)
 #endif
-template <int MT, int NT, int NS_BK = 32, int PD = 1, bool ATANH = false>
+template <int MT, int NT, int NS_BK = 32, int PD = 1, bool ATANH = false, bool ANT = false>
 __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int NS_LD = NS_BK + 4;       // row stride in floats: 16 fragment rows start on 16 distinct 4-bank groups
@@ -700,7 +702,7 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     {                                                                                                          \
         const int kk_ = (blk_) * NS_BK + c4;                                                                   \
         const long long ko_ = aplain ? (long long)kk_ : a_k_off(p, kk_);                                       \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[sl_][j] = ldg4(ag[j] + ko_);                         \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[sl_][j] = ANT ? ldg4_nt(ag[j] + ko_) : ldg4(ag[j] + ko_); \
         if (atanh_) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) rx[sl_][ATANH ? j : 0] = ldg4(xg[j] + kk_); } \
         _Pragma("unroll") for (int j = 0; j < WJ; ++j) rw[sl_][j] = ldg4(wg[j] + kk_);                         \
     }
@@ -863,7 +865,7 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
 }
 
 // single-descriptor launch of the LDS-tiled GEMM (conv2 implicit GEMM at M ~ 36 k rows): 2-D grid, descriptor in kernarg
-template <int MT, int NT, int BK = 32, int PD = 2, bool ATANH = false>
+template <int MT, int NT, int BK = 32, int PD = 2, bool ATANH = false, bool ANT = false>
 __global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb, int ntn, int ntm) {
     // 1-D grid per descriptor, dealt round-robin over the 8 XCDs: XCD x runs M-tiles x, x+8, ... and, back to back, all
     // column tiles of each, so an A row block (for conv2: 590 KB of implicit-GEMM input) is fetched into ONE L2 instead
@@ -872,7 +874,7 @@ __global__ __launch_bounds__(256) void gemm_ns(GemmBatch gb, int ntn, int ntm) {
     const int xcd = id & 7, slot = id >> 3;
     const int mt = (slot / ntn) * 8 + xcd;
     if (mt >= ntm) return;
-    gemm_ns_body<MT, NT, BK, PD, ATANH>(gb.g[blockIdx.z], slot % ntn, mt);
+    gemm_ns_body<MT, NT, BK, PD, ATANH, ANT>(gb.g[blockIdx.z], slot % ntn, mt);
 }
 
 // XCD-aware work mapping (guide T1): workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with a
@@ -923,7 +925,8 @@ __global__ void conv1_relu(const float* __restrict__ x, const float* __restrict_
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) acc = fmaf(xp[kh * RNNT_IDIM + kw], w1t[(kh * 3 + kw) * RNNT_D + c], acc);
-        y1[id] = fmaxf(acc, 0.f);
+        if (n_chunks > 1) stg1_nt(y1 + id, fmaxf(acc, 0.f));   // whole slab (~180 MB): written once, read once by conv2: keep it out of L2
+        else y1[id] = fmaxf(acc, 0.f);
     }
 }
 
