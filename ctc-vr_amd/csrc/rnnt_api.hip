@@ -69,7 +69,7 @@ struct rnnt_ctx {
     int fuse_after_norm = 1;   // RNNT_FUSE_AFTER_NORM=0: keep after_norm as its own launch in the pipelined greedy path
     int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
-    float* coop_z = nullptr; int* coop_st2 = nullptr; unsigned long long* coop_key2 = nullptr;
+    unsigned long long* flow_buf = nullptr;   // greedy_flow exchange words: xh [2][64][256] | xz [2][64][256] | xa [2][4][16][16][4]
     const float *wjc = nullptr, *bjc = nullptr;   // folded joint.pred_ffn o predictor.projection
     const float *wctc = nullptr, *bctc = nullptr; // ctc_head.ctc_lo (optional)
     // beam search: state pools [rows][n_steps+1][512] (ping-pong), per-row buffers
@@ -167,6 +167,7 @@ int dmalloc(rnnt_ctx* ctx, T** p, size_t n) {
     return RNNT_OK;
 }
 
+constexpr size_t FLOW_XH_WORDS = 2 * 64 * 256, FLOW_WORDS = 2 * FLOW_XH_WORDS + 2 * 4 * 16 * 16 * 4;   // greedy_flow exchange buffers
 constexpr int WF_MERGE_MAX = 4;   // chunks of one layer per wavefront stage (rnnt_encoder_chunks), upper bound
 inline int sub_len(int T) { return ((T - 3) / 2 + 1 - 3) / 2 + 1; }   // subsampling.py:188-193
 inline int sub1_len(int T) { return (T - 3) / 2 + 1; }
@@ -588,20 +589,21 @@ int greedy_drain(rnnt_ctx* ctx, hipStream_t s, int n_frames, int done_steps) {
 // dec_ctrl[0] (frames_ready).  The control block must have been initialised on a stream this one is ordered after.
 int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total, int n_steps_override = 0, const int* nlim = nullptr) {
     if (ctx->use_coop && ctx->n_streams <= 64 && !nlim && !n_steps_override) {
-        // cooperative decoder: 64 resident workgroups, weights stationary in LDS, 3 grid barriers per evaluation
-        CoopP c;
+        // cooperative decoder: 4 x 16 resident workgroups, weights stationary in LDS, tagged-word exchanges
+        FlowP c;
         memset(&c, 0, sizeof(c));
         c.whh = ctx->whh_il; c.egate = ctx->egate; c.wjc = ctx->wjc; c.bjc = ctx->bjc; c.wout = ctx->wout; c.bout = ctx->bout;
-        c.encp = ctx->encp; c.h = ctx->h; c.c = ctx->c; c.z = ctx->coop_z; c.sel = ctx->sel; c.tok = ctx->tok; c.fidx = ctx->fidx;
-        c.nsym = ctx->nsym; c.count = ctx->count; c.tokens = ctx->tokens; c.st2 = ctx->coop_st2; c.key2 = ctx->coop_key2; c.ctrl = ctx->dec_ctrl;
+        c.encp = ctx->encp; c.h = ctx->h; c.c = ctx->c; c.sel = ctx->sel; c.tok = ctx->tok; c.fidx = ctx->fidx;
+        c.nsym = ctx->nsym; c.count = ctx->count; c.tokens = ctx->tokens; c.ctrl = ctx->dec_ctrl;
+        c.xh = ctx->flow_buf; c.xz = ctx->flow_buf + FLOW_XH_WORDS; c.xa = ctx->flow_buf + 2 * FLOW_XH_WORDS;
         c.fstride_f = (long long)ctx->fstride * D; c.bstride = (long long)ctx->cfg.max_streams * D;
         c.B = ctx->n_streams; c.vocab = ctx->cfg.vocab_size; c.blank = ctx->cfg.blank_id; c.n_steps = ctx->cfg.n_steps;
         c.max_tokens = ctx->cfg.max_tokens; c.n_total = n_total;
-        c.timeout_ticks = 300000000ll;   // 3 s per barrier spin (100 MHz counter)
-        static const bool cdbg = getenv("RNNT_COOP_DBG") != nullptr;
-        c.dbg = cdbg ? reinterpret_cast<long long*>(ctx->coop_z + 64 * D) : nullptr;
-        hipLaunchKernelGGL(greedy_coop, dim3(COOP_G), dim3(256), 0, s, c);
-        LAUNCHCHK("greedy_coop");
+        c.timeout_ticks = 300000000ll;   // 3 s per wait (100 MHz counter)
+        static const bool fdbg = getenv("RNNT_COOP_DBG") != nullptr;
+        c.dbg = fdbg ? reinterpret_cast<long long*>(ctx->flow_buf + FLOW_WORDS) : nullptr;
+        hipLaunchKernelGGL(greedy_flow, dim3(FLOW_G), dim3(256), 0, s, c);
+        LAUNCHCHK("greedy_flow");
         return RNNT_OK;
     }
     DecP d;
@@ -626,12 +628,8 @@ int launch_persistent_decoder(rnnt_ctx* ctx, hipStream_t s, int n_total, int n_s
 }
 
 int init_decoder_ctrl(rnnt_ctx* ctx, hipStream_t s, int frames_ready) {
-    if (ctx->use_coop && ctx->n_streams <= 64) {
-        hipLaunchKernelGGL(coop_init, dim3(1), dim3(64), 0, s, ctx->coop_st2, ctx->coop_key2, ctx->dec_ctrl, ctx->tok, ctx->fidx, ctx->nsym,
-                           ctx->sel, ctx->count, ctx->n_streams, frames_ready);
-        LAUNCHCHK("coop_init");
-        return RNNT_OK;
-    }
+    if (ctx->use_coop && ctx->n_streams <= 64)   // tags restart at 1 every launch: no word of an earlier launch may survive
+        HIPCHK(hipMemsetAsync(ctx->flow_buf, 0, (size_t)FLOW_WORDS * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, s, ctx->dec_ctrl, 0, 32LL);
     LAUNCHCHK("fill_i32");
     hipLaunchKernelGGL(publish_frames, dim3(1), dim3(1), 0, s, ctx->dec_ctrl, frames_ready);
@@ -666,11 +664,11 @@ int finish_persistent_decoder(rnnt_ctx* ctx, hipStream_t s) {
     HIPCHK(hipStreamSynchronize(s));
     ctx->greedy_steps += ctx->pinned[14];
     if (getenv("RNNT_COOP_DBG") && ctx->use_coop && ctx->n_streams <= 64) {
-        long long t[8];
-        (void)hipMemcpy(t, ctx->coop_z + 64 * D, sizeof(t), hipMemcpyDeviceToHost);
-        const double ev = ctx->pinned[14] > 0 ? ctx->pinned[14] : 1;
-        fprintf(stderr, "[coop] evals %d; us/eval: decide %.2f, L %.2f, bar1 %.2f, J %.2f, bar2 %.2f, O %.2f, bar3 %.2f\n", ctx->pinned[14],
-                t[0] / ev / 100.0, t[1] / ev / 100.0, t[2] / ev / 100.0, t[3] / ev / 100.0, t[4] / ev / 100.0, t[5] / ev / 100.0, t[6] / ev / 100.0);
+        long long t[16];
+        (void)hipMemcpy(t, ctx->flow_buf + FLOW_WORDS, sizeof(t), hipMemcpyDeviceToHost);
+        const double ev = t[11] > 0 ? (double)t[11] : 1.0;
+        fprintf(stderr, "[flow] workgroup 0: %lld evals; us/eval: wait XA %.2f, decide+L %.2f, wait XH %.2f, J %.2f, wait XZ %.2f, O+send %.2f; polls/eval: XA %.2f XH %.2f XZ %.2f\n",
+                t[11], t[0] / ev / 100.0, t[1] / ev / 100.0, t[2] / ev / 100.0, t[3] / ev / 100.0, t[4] / ev / 100.0, t[5] / ev / 100.0, t[8] / ev, t[9] / ev, t[10] / ev);
     }
     if (ctx->pinned[13] != 0) return fail(ctx, RNNT_ERR_STATE, "persistent decoder gave up (code %d: 1 = frame wait, 2 = barrier, 3 = idle bound)", ctx->pinned[13]);
     return RNNT_OK;
@@ -741,7 +739,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     ALLOC(pred, (size_t)B * D); ALLOC(z, (size_t)B * D); ALLOC(logits, (size_t)B * ctx->vpad);
     ALLOC(tok, B); ALLOC(fidx, B); ALLOC(nsym, B); ALLOC(count, B); ALLOC(tokens, (size_t)B * cfg->max_tokens);
     ALLOC(n_active, 4); ALLOC(klen, B); ALLOC(dec_ctrl, 32);
-    ALLOC(coop_z, 64 * D + 64); ALLOC(coop_st2, 2 * 5 * 64); ALLOC(coop_key2, 2 * 64);
+    ALLOC(flow_buf, FLOW_WORDS + 16);
     if (cfg->max_beam > 0) {
         ctx->max_rows = B * cfg->max_beam;
         const size_t R = ctx->max_rows, NS = cfg->n_steps, KB = cfg->max_beam;
@@ -763,7 +761,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
 void rnnt_destroy(rnnt_ctx* ctx) {
     if (!ctx) return;
     void* ptrs[] = {ctx->blob, ctx->egate, ctx->y1, ctx->y2, ctx->x, ctx->hbuf, ctx->qbuf, ctx->abuf, ctx->dbuf, ctx->kcache, ctx->vcache,
-                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->dec_ctrl, ctx->coop_z, ctx->coop_st2, ctx->coop_key2, ctx->pred, ctx->z, ctx->logits,
+                    ctx->gring, ctx->xring, ctx->encbuf, ctx->encp, ctx->h, ctx->c, ctx->sel, ctx->key, ctx->dec_ctrl, ctx->flow_buf, ctx->pred, ctx->z, ctx->logits,
                     ctx->tok, ctx->fidx, ctx->nsym, ctx->count, ctx->tokens, ctx->n_active, ctx->klen, ctx->scratch,
                     ctx->pool[0], ctx->pool[1], ctx->bpred, ctx->bz, ctx->blogits, ctx->b_blank, ctx->b_toplp, ctx->b_toptok,
                     ctx->b_tok, ctx->b_frame, ctx->b_active, ctx->b_steps, ctx->b_srcrow, ctx->b_srcstep};

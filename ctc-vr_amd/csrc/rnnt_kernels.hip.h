@@ -1665,246 +1665,300 @@ __global__ void unpack_keys(const unsigned long long* __restrict__ key, int* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// greedy_coop: cooperative, weights-STATIONARY greedy decoder for B <= 64 streams.  64 resident workgroups; workgroup
-// g keeps rows [16g,16g+16) of W_hh (all 64), of the folded joint matrix W_c (g < 16) and of W_out (g < 26) in LDS for
-// the whole call, so an evaluation moves only activations: every workgroup computes its 16 output columns for ALL
-// streams with exact-f32 MFMAs (M = 64 streams), and the three dependent products of an evaluation
-//     gates = E[tok] + h W_hh^T  ->  z = tanh(enc_proj[t] + h' W_c^T + b_c)  ->  logits = z W_out^T + b_out -> argmax
-// are separated by three grid-wide counter barriers.  The per-stream persistent kernel above streams 1.7 MB of
-// weights per evaluation from L2 (~23 us at the ~70 GB/s one CU gets, and it thrashes the L2 the encoder needs);
-// here nothing but ~200 KB of activations crosses L2 per evaluation.
-// Inter-workgroup protocol (guide, Guideline 16 R1): every exchanged word is written with a relaxed agent-scope atomic
-// store (write-through, sc1), every storing wave drains vmcnt before the workgroup arrives at the barrier (one
-// agent-scope atomic add), the poller spins on a relaxed agent-scope load, and every exchanged word is read with
-// relaxed agent-scope atomic loads (bypass the non-coherent L1).  All spins are bounded by the wall clock; a timeout
-// or an abort raised by another workgroup makes every workgroup leave.
+// greedy_flow: cooperative, weights-STATIONARY greedy decoder for B <= 64 streams (experiment, RNNT_COOP=1).
+// Workgroup g = sg * 16 + cg owns streams [16 sg, 16 sg + 16) and column group cg of every weight matrix, resident in
+// LDS for the whole call: W_hh rows [64 cg, +64) (16 hidden units x 4 gates), W_c rows [16 cg, +16), W_out rows
+// [26 cg, +26).  An evaluation is three exchanges among the 16 workgroups of a stream group
+//     h' slices  ->  z slices  ->  per-workgroup argmax partials (+ frames_ready from cg 0)
+// and every exchanged 32-bit value travels as ONE 8-byte word (payload | tag << 32, tag = evaluation number), written
+// with a single write-through store and read with an L1-bypassing load: a word is valid iff its tag matches, so there
+// is no counter, no store drain and no fence on the exchange path -- a consumer's cost is the round trips it needs to
+// see all its words (the barrier-based predecessor paid ~10 us per exchange for drain + atomic + poll + load).  Buffers
+// alternate by evaluation parity; a workgroup can only be one exchange ahead of the slowest of its group, so a slot is
+// never rewritten before every reader has passed it.  Every workgroup derives the same decisions from the same words
+// and keeps the stream state (token, frame, counts) privately; cell states live in registers of the lanes that own them.
+// The predictor is re-evaluated only for streams that emitted (dirty), as in greedy_stream.  Spins are wall-clock bounded.
 // ------------------------------------------------------------------------------------------------
-struct CoopP {
+struct FlowP {
     const float* whh; const float* egate; const float* wjc; const float* bjc; const float* wout; const float* bout;
     const float* encp;
-    float* h; float* c;          // [2][bstride] state buffers
-    float* z;                    // [64][256] exchange buffer for the joint activations
+    float* h; float* c;                 // [2][bstride] state buffers (committed one by sel[]; written back to buffer 0)
     int* sel; int* tok; int* fidx; int* nsym; int* count; int* tokens;
-    int* st2;                    // [2][5][64] ping-pong copy of (tok, fidx, nsym, sel, count) by evaluation parity
-    unsigned long long* key2;    // [2][64] packed argmax by evaluation parity
-    int* ctrl;                   // [0] frames_ready, [1] error, [2] evaluations, [3] barrier counter, [4] abort, [5..6] nf by parity
+    unsigned long long* xh;             // [2][64][256] tagged h' words
+    unsigned long long* xz;             // [2][64][256] tagged z words
+    unsigned long long* xa;             // [2][4][16][16][4] tagged (ordered max, index, frames_ready, -) per (group, workgroup, stream)
+    int* ctrl;                          // [0] frames_ready, [1] error, [2] evaluations, [4] abort
     long long fstride_f, bstride;
     int B, vocab, blank, n_steps, max_tokens, n_total;
     long long timeout_ticks;
-    long long* dbg;              // optional [8] phase timers (100 MHz ticks, workgroup 0), null = off
+    long long* dbg;                     // optional [16]: phase timers (100 MHz ticks) and poll iterations of workgroup 0
 };
 
 __device__ __forceinline__ float ld_sc1f(const float* p) {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ void st_sc1f(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ int ld_sc1i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_tag(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_tag(unsigned long long* p, unsigned payload, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-#define COOP_G 64      // workgroups: 4 stream groups x 16 column groups
-#define COOP_CG 16
-#define COOP_LD 260
-// barrier among the 16 workgroups of one stream group; returns false when the launch must be abandoned
-__device__ __forceinline__ bool coop_barrier(const CoopP& p, int* counter, int target, int* s_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
+#define FLOW_G 64      // workgroups: 4 stream groups x 16 column groups
+#define FLOW_CG 16
+#define FLOW_LD 260
+#define FLOW_NONE 0x7fffffff
+
+// wait until all NW words of this thread carry `tag`; false = abort (timeout or another workgroup gave up)
+template <int NW>
+__device__ __forceinline__ bool flow_wait(const FlowP& p, const unsigned long long* src, unsigned tag, unsigned* out, int* s_flag, long long* polls) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while (true) {
+        ++*polls;
+        unsigned long long v[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) v[j] = ld_tag(src + j);
         int ok = 1;
-        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-        while (ld_sc1i(counter) < target) {
-            if (ld_sc1i(p.ctrl + 4) != 0) { ok = 0; break; }
-            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            ok &= (unsigned)(v[j] >> 32) == tag ? 1 : 0;
+            out[j] = (unsigned)v[j];
+        }
+        if (__syncthreads_and(ok)) return true;
+        if (threadIdx.x == 0) {
+            int bad = ld_sc1i(p.ctrl + 4) != 0 ? 1 : 0;
+            if (!bad && (long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                 st_sc1i(p.ctrl + 1, 2);
                 st_sc1i(p.ctrl + 4, 1);
-                ok = 0;
-                break;
+                bad = 1;
             }
-            __builtin_amdgcn_s_sleep(1);
+            *s_flag = bad;
         }
-        *s_flag = ok;
-    }
-    __syncthreads();
-    return *s_flag != 0;
-}
-
-// stage the 16 rows of my stream group (256 floats each) into X[16][COOP_LD] with sc1 loads, all issued before any store
-template <typename RowOff>
-__device__ __forceinline__ void coop_stage(float* X, const float* base, int nrows, RowOff row_off) {
-    const int tid = threadIdx.x;
-    unsigned long long v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int e = tid + 256 * j;
-        const int r = e >> 7, c2 = (e & 127) * 2;
-        v[j] = 0ull;
-        if (r < nrows) v[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(base + row_off(r) + c2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int e = tid + 256 * j;
-        *reinterpret_cast<unsigned long long*>(&X[(e >> 7) * COOP_LD + (e & 127) * 2]) = v[j];
+        __syncthreads();
+        if (*s_flag) return false;
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
-// 2-D partition: workgroup g = sg * 16 + cg owns streams [16 sg, 16 sg + 16) and, of every weight matrix, the rows of
-// column group cg: W_hh rows [64 cg, +64) (16 hidden units x 4 gates), W_c rows [16 cg, +16), W_out rows [26 cg, +26).
-// A workgroup therefore gathers only ITS 16 streams' activations (16 KB per phase) and synchronises only with the 15
-// workgroups of its stream group; the 4 stream groups advance independently.
-// ctrl: [0] frames_ready [1] error [2] evaluations [4] abort [8+sg] barrier counters [16 + 2 sg + par] frames seen by group sg
-__global__ __launch_bounds__(256) void greedy_coop(CoopP p) {
-    __shared__ __attribute__((aligned(16))) float Wl[64 * COOP_LD], Wj[16 * COOP_LD], Wo[32 * COOP_LD];
-    __shared__ __attribute__((aligned(16))) float X[16 * COOP_LD];
+__global__ __launch_bounds__(256) void greedy_flow(FlowP p) {
+    __shared__ __attribute__((aligned(16))) float Wl[64 * FLOW_LD], Wj[16 * FLOW_LD], Wo[32 * FLOW_LD];
+    __shared__ __attribute__((aligned(16))) float Hn[16 * FLOW_LD];     // h' of every stream (= committed h of the streams that emitted)
+    __shared__ __attribute__((aligned(16))) float X[16 * FLOW_LD];      // z of every stream
     __shared__ __attribute__((aligned(16))) float red[4 * 256];
-    __shared__ int s_tok[16], s_fidx[16], s_nsym[16], s_sel[16], s_count[16], s_act[16];
-    __shared__ int s_flag, s_done, s_nf, s_any;
+    __shared__ int s_tok[16], s_fidx[16], s_nsym[16], s_count[16], s_act[16], s_had[16], s_dirty[16], s_emit[16];
+    __shared__ unsigned s_pv[16][16];
+    __shared__ int s_pi[16][16];
+    __shared__ unsigned s_bv[2][16];
+    __shared__ int s_bi[2][16];
+    __shared__ int s_flag, s_nf, s_done, s_any;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sg = blockIdx.x / COOP_CG, cg = blockIdx.x % COOP_CG;
+    const int sg = blockIdx.x / FLOW_CG, cg = blockIdx.x % FLOW_CG;
     const int i = lane & 15, kq = lane >> 4;
     const int b0 = 16 * sg;
-    const int nb = min(16, p.B - b0);        // streams of my group (<= 0: the group has nothing to do)
-    if (nb <= 0) return;                      // whole stream group absent: all its 16 workgroups leave
+    const int nb = min(16, p.B - b0);
+    if (nb <= 0) return;                                       // the whole stream group is absent
     // ---- resident weight slices ---------------------------------------------------------------------------------------
     for (int e = tid; e < 64 * 64; e += 256) {
         const int r = e >> 6, c4 = (e & 63) * 4;
-        *reinterpret_cast<float4*>(&Wl[r * COOP_LD + c4]) = ldg4(p.whh + (long long)(64 * cg + r) * RNNT_D + c4);
-        if (r < 16) *reinterpret_cast<float4*>(&Wj[r * COOP_LD + c4]) = ldg4(p.wjc + (long long)(16 * cg + r) * RNNT_D + c4);
-        if (r < 32) *reinterpret_cast<float4*>(&Wo[r * COOP_LD + c4]) = ldg4(p.wout + (long long)min(26 * cg + min(r, 25), p.vocab - 1) * RNNT_D + c4);
+        *reinterpret_cast<float4*>(&Wl[r * FLOW_LD + c4]) = ldg4(p.whh + (long long)(64 * cg + r) * RNNT_D + c4);
+        if (r < 16) *reinterpret_cast<float4*>(&Wj[r * FLOW_LD + c4]) = ldg4(p.wjc + (long long)(16 * cg + r) * RNNT_D + c4);
+        if (r < 32) *reinterpret_cast<float4*>(&Wo[r * FLOW_LD + c4]) = ldg4(p.wout + (long long)min(26 * cg + min(r, 25), p.vocab - 1) * RNNT_D + c4);
     }
-    int* bar_ctr = p.ctrl + 8 + sg;
-    int bar = 0, seen_nf = 0, evals = 0;
-    const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = t_start;
-#define COOP_T(k) { if (p.dbg && blockIdx.x == 0 && tid == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tl; tl = t_; } }
+    // ---- private copy of the streams' state --------------------------------------------------------------------------------
+    {
+        const int m = tid >> 4, c16 = (tid & 15) * 16;
+        const int bb = b0 + min(m, nb - 1);
+        const float* hp = p.h + (long long)(ldgi(p.sel + bb) & 1) * p.bstride + (long long)bb * RNNT_D + c16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Hn[m * FLOW_LD + c16 + 4 * j]) = ldg4(hp + 4 * j);
+    }
+    if (tid < 16) {
+        const bool v = tid < nb;
+        const int bb = b0 + tid;
+        s_tok[tid] = v ? ldgi(p.tok + bb) : p.blank;
+        s_fidx[tid] = v ? ldgi(p.fidx + bb) : p.n_total;
+        s_nsym[tid] = v ? ldgi(p.nsym + bb) : 0;
+        s_count[tid] = v ? ldgi(p.count + bb) : 0;
+        s_act[tid] = 0; s_had[tid] = 0; s_dirty[tid] = 1; s_emit[tid] = 0;
+    }
+    // cell state of my (stream 4 kq + r, unit 16 cg + 4 wave + i / 4), held by the lanes with i % 4 == 0
+    const int unit = 16 * cg + 4 * wave + (i >> 2);
+    float cc[4], hc[4], cc2[4], hh2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int bb = b0 + min(4 * kq + r, nb - 1);
+        const long long off = (long long)(ldgi(p.sel + bb) & 1) * p.bstride + (long long)bb * RNNT_D + unit;
+        cc[r] = ldg1(p.c + off);
+        hc[r] = ldg1(p.h + off);
+        cc2[r] = cc[r];
+        hh2[r] = hc[r];
+    }
+    unsigned e = 1;                                            // evaluation number = tag
+    int seen_nf = 0, evals = 0;
+    long long polls[3] = {0, 0, 0}, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = (long long)__builtin_amdgcn_s_memrealtime();
+#define FLOW_T(k) { if (p.dbg && blockIdx.x == 0 && tid == 0) { const long long t_ = (long long)__builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tl; tl = t_; } }
+    // round 0: no argmax yet, only frames_ready from cg 0
+    if (tid < 16) {
+        unsigned long long* q = p.xa + ((((size_t)(e & 1) * 4 + sg) * 16 + cg) * 16 + tid) * 4;
+        st_tag(q + 0, 0u, e);
+        st_tag(q + 1, (unsigned)FLOW_NONE, e);
+        st_tag(q + 2, cg == 0 ? (unsigned)ld_sc1i(p.ctrl) : 0u, e);
+    }
     __syncthreads();
-    for (int ev = 0;; ++ev) {
-        const int par = ev & 1;
-        int* st_in = p.st2 + par * 5 * 64;
-        int* st_out = p.st2 + (par ^ 1) * 5 * 64;
-        // ---- D: apply the previous argmax of my 16 streams (all 16 workgroups of the group recompute; cg == 0 records) --
-        if (tid < 16) {
-            const int b = b0 + tid;
-            int tokv = p.blank, f = p.n_total, ns = 0, sl = 0, cnt = 0, act = 0;
-            const int nf = ld_sc1i(p.ctrl + 16 + 2 * sg + par);
-            if (tid < nb) {
-                tokv = ld_sc1i(st_in + 0 * 64 + b); f = ld_sc1i(st_in + 1 * 64 + b); ns = ld_sc1i(st_in + 2 * 64 + b);
-                sl = ld_sc1i(st_in + 3 * 64 + b); cnt = ld_sc1i(st_in + 4 * 64 + b);
-                const unsigned long long k64 = __hip_atomic_load(p.key2 + par * 64 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k64 != 0ull) {
-                    const int k = (int)(0xFFFFFFFFu - (unsigned)(k64 & 0xFFFFFFFFull));
-                    if (k == p.blank) { f += 1; ns = 0; }
-                    else {
-                        if (cg == 0 && cnt < p.max_tokens) p.tokens[(long long)b * p.max_tokens + cnt] = k;
-                        cnt += 1; tokv = k; sl ^= 1; ns += 1;
-                        if (ns >= p.n_steps) { ns = 0; f += 1; }
-                    }
-                }
-                act = f < nf ? 1 : 0;
-                if (cg == 0) {
-                    st_sc1i(st_out + 0 * 64 + b, tokv); st_sc1i(st_out + 1 * 64 + b, f); st_sc1i(st_out + 2 * 64 + b, ns);
-                    st_sc1i(st_out + 3 * 64 + b, sl); st_sc1i(st_out + 4 * 64 + b, cnt);
-                    __hip_atomic_store(p.key2 + (par ^ 1) * 64 + b, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            s_tok[tid] = tokv; s_fidx[tid] = f; s_nsym[tid] = ns; s_sel[tid] = sl; s_count[tid] = cnt; s_act[tid] = act;
-            const unsigned long long m16 = 0xFFFFull;
-            const unsigned long long anyact = __ballot(act != 0) & m16, notdone = __ballot(tid < nb && f < p.n_total) & m16;
-            if (tid == 0) { s_done = notdone == 0ull ? 1 : 0; s_nf = nf; s_any = anyact != 0ull ? 1 : 0; }
+    while (true) {
+        const unsigned par = e & 1;
+        FLOW_T(5)
+        // ---- D: gather the 16 partials of every stream, decide -----------------------------------------------------------
+        {
+            unsigned w3[3];
+            const int wg = tid >> 4, m = tid & 15;
+            if (!flow_wait<3>(p, p.xa + ((((size_t)par * 4 + sg) * 16 + wg) * 16 + m) * 4, e, w3, &s_flag, &polls[0])) return;
+            FLOW_T(0)
+            s_pv[wg][m] = w3[0];
+            s_pi[wg][m] = (int)w3[1];
+            if (tid == 0) s_nf = (int)w3[2];
         }
         __syncthreads();
-        COOP_T(0)
+        if (tid < 16) {
+            const int m = tid;
+            unsigned bv = 0u;
+            int bi = FLOW_NONE;
+            for (int g = 0; g < 16; ++g) {
+                const unsigned v = s_pv[g][m];
+                const int ix = s_pi[g][m];
+                if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+            }
+            int emit = 0;
+            if (s_had[m] && bi != FLOW_NONE) {
+                if (bi == p.blank) { s_fidx[m] += 1; s_nsym[m] = 0; }
+                else {
+                    const int cnt = s_count[m];
+                    if (cg == 0 && cnt < p.max_tokens) p.tokens[(long long)(b0 + m) * p.max_tokens + cnt] = bi;
+                    s_count[m] = cnt + 1;
+                    s_tok[m] = bi;
+                    const int ns = s_nsym[m] + 1;
+                    if (ns >= p.n_steps) { s_nsym[m] = 0; s_fidx[m] += 1; } else { s_nsym[m] = ns; }
+                    s_dirty[m] = 1;
+                    emit = 1;
+                }
+            }
+            s_emit[m] = emit;
+            const int f = s_fidx[m];
+            const int act = (m < nb && f < p.n_total && f < s_nf) ? 1 : 0;
+            s_act[m] = act;
+            const unsigned long long m16 = 0xFFFFull;
+            const unsigned long long anyact = __ballot(act != 0) & m16, notdone = __ballot(m < nb && f < p.n_total) & m16;
+            if (m == 0) { s_done = notdone == 0ull ? 1 : 0; s_any = anyact != 0ull ? 1 : 0; }
+        }
+        __syncthreads();
+        // commit the cell / hidden state of the streams that emitted (their Hn row already is the new h)
+        if ((i & 3) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (s_emit[4 * kq + r]) { cc[r] = cc2[r]; hc[r] = hh2[r]; }
+        }
         if (s_done) break;
-        const bool anyact = s_any != 0;
         if (s_nf > seen_nf) {   // new encoder frames were published: one agent-scope acquire before reading enc_proj rows
             if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             seen_nf = s_nf;
             __syncthreads();
         }
+        const bool anyact = s_any != 0;
         if (anyact) {
-            // ---- L: gates of my 16 hidden units for my 16 streams; candidate (h', c') -------------------------------------
-            coop_stage(X, p.h, nb, [&](int r) { return (long long)s_sel[r] * p.bstride + (long long)(b0 + r) * RNNT_D; });
-            __syncthreads();
-            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+            // ---- L: gates of my 16 units for the 16 streams; new candidate (h', c') only where the predictor input changed ----
+            {
+                f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-            for (int u = 0; u < 16; ++u) {
-                const float4 a = *reinterpret_cast<const float4*>(&X[i * COOP_LD + 16 * u + 4 * kq]);
-                const float4 w = *reinterpret_cast<const float4*>(&Wl[(16 * wave + i) * COOP_LD + 16 * u + 4 * kq]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 4 * kq + r;                          // local stream
-                const int mm = min(m, nb - 1);
+                for (int u = 0; u < 16; ++u) {
+                    const float4 a = *reinterpret_cast<const float4*>(&Hn[i * FLOW_LD + 16 * u + 4 * kq]);
+                    const float4 w = *reinterpret_cast<const float4*>(&Wl[(16 * wave + i) * FLOW_LD + 16 * u + 4 * kq]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+                }
                 const int n = 64 * cg + 16 * wave + i;             // gate column (interleaved i,f,g,o)
-                float v = acc[r] + ldg1(p.egate + (long long)s_tok[mm] * (4 * RNNT_D) + n);
-                const float gf = __shfl_down(v, 1, 64), gg = __shfl_down(v, 2, 64), go = __shfl_down(v, 3, 64);
-                if ((i & 3) == 0 && m < nb) {
-                    const long long so = (long long)(b0 + m) * RNNT_D + (n >> 2);
-                    const float cin = ld_sc1f(p.c + (long long)s_sel[m] * p.bstride + so);
-                    const float c2v = sigmoidf_(gf) * cin + sigmoidf_(v) * tanhf(gg);
-                    st_sc1f(p.c + (long long)(s_sel[m] ^ 1) * p.bstride + so, c2v);
-                    st_sc1f(p.h + (long long)(s_sel[m] ^ 1) * p.bstride + so, sigmoidf_(go) * tanhf(c2v));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 4 * kq + r;
+                    const float v = acc[r] + ldg1(p.egate + (long long)s_tok[m] * (4 * RNNT_D) + n);
+                    const float gf = __shfl_down(v, 1, 64), gg = __shfl_down(v, 2, 64), go = __shfl_down(v, 3, 64);
+                    if ((i & 3) == 0) {
+                        if (s_dirty[m] && m < nb) {
+                            const float c2v = sigmoidf_(gf) * cc[r] + sigmoidf_(v) * tanhf(gg);
+                            cc2[r] = c2v;
+                            hh2[r] = sigmoidf_(go) * tanhf(c2v);
+                        }
+                        st_tag(p.xh + ((size_t)par * 64 + b0 + m) * RNNT_D + unit, __float_as_uint(hh2[r]), e);
+                    }
                 }
             }
-        }
-        COOP_T(1)
-        if (!coop_barrier(p, bar_ctr, COOP_CG * (++bar), &s_flag)) return;
-        COOP_T(2)
-        if (anyact) {
-            // ---- J: z = tanh(enc_proj[t] + h' W_c^T + b_c), my 16 columns; K split over the 4 waves ------------------------
-            coop_stage(X, p.h, nb, [&](int r) { return (long long)(s_sel[r] ^ 1) * p.bstride + (long long)(b0 + r) * RNNT_D; });
-            __syncthreads();
-            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+            __syncthreads();                                       // everybody has read Hn and s_dirty
+            if (tid < 16) s_dirty[tid] = 0;
+            // ---- J: all h' of my streams -> z = tanh(enc_proj[t] + h' W_c^T + b_c), my 16 columns ------------------------------
+            {
+                unsigned w16[16];
+                const int m = tid >> 4, c16 = (tid & 15) * 16;
+                FLOW_T(1)
+                if (!flow_wait<16>(p, p.xh + ((size_t)par * 64 + b0 + m) * RNNT_D + c16, e, w16, &s_flag, &polls[1])) return;
+                FLOW_T(2)
 #pragma unroll
-            for (int u = 4 * wave; u < 4 * wave + 4; ++u) {
-                const float4 a = *reinterpret_cast<const float4*>(&X[i * COOP_LD + 16 * u + 4 * kq]);
-                const float4 w = *reinterpret_cast<const float4*>(&Wj[i * COOP_LD + 16 * u + 4 * kq]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+                for (int j = 0; j < 16; ++j) Hn[m * FLOW_LD + c16 + j] = __uint_as_float(w16[j]);
             }
+            __syncthreads();
+            {
+                f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
+                for (int u = 4 * wave; u < 4 * wave + 4; ++u) {
+                    const float4 a = *reinterpret_cast<const float4*>(&Hn[i * FLOW_LD + 16 * u + 4 * kq]);
+                    const float4 w = *reinterpret_cast<const float4*>(&Wj[i * FLOW_LD + 16 * u + 4 * kq]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
+            }
             __syncthreads();
             {   // 256 outputs (16 streams x 16 columns), one per thread
                 const int r = tid >> 6, ln = tid & 63;
                 const float sum = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
                 const int m = 4 * (ln >> 4) + r, n = 16 * cg + (ln & 15);
-                if (m < nb) {
-                    float e = 0.f;
-                    if (s_act[m]) e = ldg1(p.encp + (long long)(b0 + m) * p.fstride_f + (long long)s_fidx[m] * RNNT_D + n);
-                    st_sc1f(p.z + (long long)(b0 + m) * RNNT_D + n, tanhf(sum + ldg1(p.bjc + n) + e));
+                float ev = 0.f;
+                if (s_act[m]) ev = ldg1(p.encp + (long long)(b0 + m) * p.fstride_f + (long long)s_fidx[m] * RNNT_D + n);
+                st_tag(p.xz + ((size_t)par * 64 + b0 + m) * RNNT_D + n, __float_as_uint(tanhf(sum + ldg1(p.bjc + n) + ev)), e);
+            }
+            // ---- O: all z of my streams -> logits of my 26 vocabulary rows -> argmax partial ----------------------------------------
+            {
+                unsigned w16[16];
+                const int m = tid >> 4, c16 = (tid & 15) * 16;
+                FLOW_T(3)
+                if (!flow_wait<16>(p, p.xz + ((size_t)par * 64 + b0 + m) * RNNT_D + c16, e, w16, &s_flag, &polls[2])) return;
+                FLOW_T(4)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) X[m * FLOW_LD + c16 + j] = __uint_as_float(w16[j]);
+            }
+            __syncthreads();
+            {
+                const int tile = wave >> 1, kh = wave & 1;
+                f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 8 * kh; u < 8 * kh + 8; ++u) {
+                    const float4 a = *reinterpret_cast<const float4*>(&X[i * FLOW_LD + 16 * u + 4 * kq]);
+                    const float4 w = *reinterpret_cast<const float4*>(&Wo[(16 * tile + i) * FLOW_LD + 16 * u + 4 * kq]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
                 }
-            }
-        }
-        COOP_T(3)
-        if (!coop_barrier(p, bar_ctr, COOP_CG * (++bar), &s_flag)) return;
-        COOP_T(4)
-        if (anyact) {
-            // ---- O: logits of my 26 vocabulary rows (2 tiles x 2 K halves over the 4 waves) + argmax into the packed key ----
-            coop_stage(X, p.z, nb, [&](int r) { return (long long)(b0 + r) * RNNT_D; });
-            __syncthreads();
-            const int tile = wave >> 1, kh = wave & 1;
-            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 8 * kh; u < 8 * kh + 8; ++u) {
-                const float4 a = *reinterpret_cast<const float4*>(&X[i * COOP_LD + 16 * u + 4 * kq]);
-                const float4 w = *reinterpret_cast<const float4*>(&Wo[(16 * tile + i) * COOP_LD + 16 * u + 4 * kq]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = acc[r];
             __syncthreads();
-            if (tid < 128) {   // 2 tiles x (4 regs x 64 lanes) -> thread handles (tile, r, lane)
+            if (tid < 128) {   // 2 tiles x (4 regs x 64 lanes): thread = (tile, lane), loops the 4 regs
                 const int t2 = tid >> 6, ln = tid & 63;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1914,56 +1968,69 @@ __global__ __launch_bounds__(256) void greedy_coop(CoopP p) {
                     const int n = 26 * cg + jr;
                     const bool nin = jr < 26 && n < p.vocab;
                     float v = nin ? sum + ldg1(p.bout + min(n, p.vocab - 1)) : -INFINITY;
-                    int bi = nin ? n : 0x7fffffff;
+                    int bi = nin ? n : FLOW_NONE;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) {
                         const float ov = __shfl_xor(v, o, 16);
                         const int oi = __shfl_xor(bi, o, 16);
                         if (ov > v || (ov == v && oi < bi)) { v = ov; bi = oi; }
                     }
-                    if ((ln & 15) == 0 && m < nb && s_act[m] && bi != 0x7fffffff) {
-                        unsigned uu = __float_as_uint(v);
-                        uu = (uu & 0x80000000u) ? ~uu : (uu | 0x80000000u);
-                        atomicMax(p.key2 + (par ^ 1) * 64 + b0 + m, ((unsigned long long)uu << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)bi));
+                    if ((ln & 15) == 0) {
+                        unsigned uu = 0u;
+                        if (bi != FLOW_NONE) {
+                            uu = __float_as_uint(v);
+                            uu = (uu & 0x80000000u) ? ~uu : (uu | 0x80000000u);   // order-preserving; > 0 for every real value
+                        }
+                        s_bv[t2][m] = uu;
+                        s_bi[t2][m] = bi;
                     }
                 }
             }
+            __syncthreads();
+            ++evals;
+        } else {
+            __builtin_amdgcn_s_sleep(64);                          // nothing decodable: wait for the encoder
+            if (tid < 16) { s_bv[0][tid] = 0u; s_bv[1][tid] = 0u; s_bi[0][tid] = FLOW_NONE; s_bi[1][tid] = FLOW_NONE; }
+            __syncthreads();
         }
-        if (cg == 0 && tid == 0) st_sc1i(p.ctrl + 16 + 2 * sg + (par ^ 1), ld_sc1i(p.ctrl));   // frames visible to the group's NEXT evaluation
-        if (anyact) ++evals;
-        else __builtin_amdgcn_s_sleep(64);                                                      // waiting for the encoder
-        COOP_T(5)
-        if (!coop_barrier(p, bar_ctr, COOP_CG * (++bar), &s_flag)) return;
-        COOP_T(6)
-        if (!anyact && cg == 0 && tid == 0 && (long long)__builtin_amdgcn_s_memrealtime() - t_start > 4 * p.timeout_ticks) {
-            st_sc1i(p.ctrl + 1, 3);   // the encoder never published the missing frames: abort everybody (seen in the next barrier spin)
-            st_sc1i(p.ctrl + 4, 1);
+        // ---- partial argmax of my rows + frames_ready (cg 0) for the next evaluation -------------------------------------------
+        if (tid < 16) {
+            const int m = tid;
+            unsigned bv = s_bv[0][m];
+            int bi = s_bi[0][m];
+            if (s_bv[1][m] > bv || (s_bv[1][m] == bv && s_bi[1][m] < bi)) { bv = s_bv[1][m]; bi = s_bi[1][m]; }
+            if (!s_act[m]) { bv = 0u; bi = FLOW_NONE; }
+            s_had[m] = s_act[m];
+            unsigned long long* q = p.xa + ((((size_t)((e + 1) & 1) * 4 + sg) * 16 + cg) * 16 + m) * 4;
+            st_tag(q + 0, bv, e + 1);
+            st_tag(q + 1, (unsigned)bi, e + 1);
+            st_tag(q + 2, cg == 0 ? (unsigned)ld_sc1i(p.ctrl) : 0u, e + 1);
+        }
+        __syncthreads();
+        ++e;
+    }
+    // ---- canonical state for the host / the next call (buffer 0 becomes the committed one) ---------------------------------
+    if ((i & 3) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * kq + r;
+            if (m < nb) {
+                stg1(p.h + (long long)(b0 + m) * RNNT_D + unit, hc[r]);
+                stg1(p.c + (long long)(b0 + m) * RNNT_D + unit, cc[r]);
+            }
         }
     }
-    // ---- canonical state for the host / the next call --------------------------------------------------------------------
     if (cg == 0 && tid < nb) {
         const int b = b0 + tid;
-        p.tok[b] = s_tok[tid]; p.fidx[b] = s_fidx[tid]; p.nsym[b] = s_nsym[tid]; p.sel[b] = s_sel[tid]; p.count[b] = s_count[tid];
+        p.tok[b] = s_tok[tid]; p.fidx[b] = s_fidx[tid]; p.nsym[b] = s_nsym[tid]; p.sel[b] = 0; p.count[b] = s_count[tid];
     }
     if (cg == 0 && tid == 0) atomicAdd(p.ctrl + 2, evals);
-    if (p.dbg && blockIdx.x == 0 && tid == 0)
+    if (p.dbg && blockIdx.x == 0 && tid == 0) {
         for (int k = 0; k < 8; ++k) p.dbg[k] = tacc[k];
-#undef COOP_T
-}
-
-// st2[0] <- canonical (tok, fidx, nsym, sel, count); keys <- 0; nf by parity <- frames_ready
-__global__ void coop_init(int* st2, unsigned long long* key2, int* ctrl, const int* tok, const int* fidx, const int* nsym, const int* sel,
-                          const int* count, int B, int frames_ready) {
-    const int b = threadIdx.x;
-    if (b < 64) {
-        st2[0 * 64 + b] = b < B ? tok[b] : 0; st2[1 * 64 + b] = b < B ? fidx[b] : 0; st2[2 * 64 + b] = b < B ? nsym[b] : 0;
-        st2[3 * 64 + b] = b < B ? sel[b] : 0; st2[4 * 64 + b] = b < B ? count[b] : 0;
-        key2[b] = 0ull; key2[64 + b] = 0ull;
+        for (int k = 0; k < 3; ++k) p.dbg[8 + k] = polls[k];
+        p.dbg[11] = evals;
     }
-    if (b < 32) ctrl[b] = 0;
-    __syncthreads();
-    if (b == 0) ctrl[0] = frames_ready;
-    if (b < 8) ctrl[16 + b] = frames_ready;
+#undef FLOW_T
 }
 
 // frames_ready <- n (one thread; the kernel boundary before it released the encoder's writes)
