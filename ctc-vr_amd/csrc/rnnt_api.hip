@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <array>
 #include <vector>
 
@@ -99,6 +100,10 @@ struct rnnt_ctx {
     int wf_groups = 2, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4), RNNT_WF_SUB_ASYNC
     int wf_merge = 2;                          // RNNT_WF_MERGE (1..WF_MERGE_MAX): chunks of one layer per wavefront stage
     std::vector<hipEvent_t> ev_pool;
+    // native beam bookkeeping (rnnt_beam_advance): per stream, hypotheses in device-row order
+    struct Hyp { std::vector<int> tokens; double log_prob; };
+    std::vector<std::vector<Hyp>> beams;
+    int use_beam_chain = 1;    // RNNT_BEAM_CHAIN=0: launched extension steps (5 kernels + one host sync per step)
     // feature front-end (rnnt_fbank): DFT / mel matrices for (fb_rate, fb_nfft) and grow-only work buffers
     float *fb_dft = nullptr, *fb_mel = nullptr, *fb_pad = nullptr, *fb_spec = nullptr, *fb_pow = nullptr;
     size_t fb_pad_cap = 0, fb_spec_cap = 0, fb_pow_cap = 0;
@@ -707,6 +712,7 @@ int rnnt_create(const rnnt_config* cfg, rnnt_ctx** out) {
     if (const char* pe = getenv("RNNT_PERSISTENT")) ctx->use_persistent = (pe[0] == '0') ? 0 : 1;
     if (const char* ce = getenv("RNNT_COOP")) ctx->use_coop = (ce[0] == '0') ? 0 : 1;
     if (const char* ae = getenv("RNNT_ATTN_STREAM")) ctx->attn_stream = (ae[0] == '0') ? 0 : 1;
+    if (const char* be = getenv("RNNT_BEAM_CHAIN")) ctx->use_beam_chain = (be[0] == '0') ? 0 : 1;
     if (const char* fe = getenv("RNNT_FUSE_AFTER_NORM")) ctx->fuse_after_norm = (fe[0] == '0') ? 0 : 1;
     if (const char* ge = getenv("RNNT_WF_GROUPS")) { const int g = atoi(ge); ctx->wf_groups = g < 1 ? 1 : (g > 4 ? 4 : g); }
     if (const char* me = getenv("RNNT_WF_MERGE")) { const int m = atoi(me); ctx->wf_merge = m < 1 ? 1 : (m > WF_MERGE_MAX ? WF_MERGE_MAX : m); }
@@ -1028,6 +1034,7 @@ int rnnt_streams_reset(rnnt_ctx* ctx, int32_t n_streams, void* stream) {
     hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, s, ctx->tok, ctx->cfg.blank_id, (long long)B);
     LAUNCHCHK("fill_i32");
     if (ctx->max_rows > 0) {   // one empty hypothesis per stream with the zero LSTM state (online_rnnt_model.py:407-415)
+        ctx->beams.assign(n_streams, std::vector<rnnt_ctx::Hyp>(1, rnnt_ctx::Hyp{{}, 0.0}));
         ctx->pool_cur = 0;
         HIPCHK(hipMemsetAsync(ctx->pool[0], 0, (size_t)ctx->max_rows * (ctx->cfg.n_steps + 1) * 512 * sizeof(float), s));
     }
@@ -1499,6 +1506,17 @@ int rnnt_beam_frame(rnnt_ctx* ctx, int32_t frame_idx, int32_t n_rows, const int3
     float* pool = ctx->pool[ctx->pool_cur];
     BeamOut bo{ctx->b_active, ctx->b_tok, ctx->b_steps, ctx->b_blank, ctx->b_toplp, ctx->b_toptok, ctx->n_active + 1};
     int rc;
+    if (ctx->use_beam_chain && V <= 512) {   // one resident workgroup per row runs its whole extension chain
+        BeamChainP c;
+        memset(&c, 0, sizeof(c));
+        c.whh = ctx->whh_il; c.egate = ctx->egate; c.wpr = ctx->wpr; c.bpr = ctx->bpr; c.wpf = ctx->wpf; c.bpf = ctx->bpf;
+        c.wout = ctx->wout; c.bout = ctx->bout; c.encp = ctx->encp; c.pool = pool; c.frame = ctx->b_frame; c.tok_in = ctx->b_tok;
+        c.steps = ctx->b_steps; c.blank_lp = ctx->b_blank; c.top_lp = ctx->b_toplp; c.top_tok = ctx->b_toptok;
+        c.vocab = V; c.blank = ctx->cfg.blank_id; c.k = beam_k; c.n_steps = NS; c.slots = slots;
+        hipLaunchKernelGGL(beam_chain, dim3(R), dim3(512), 0, s, c);
+        LAUNCHCHK("beam_chain");
+        ctx->launches += 1;
+    } else
     for (int st = 0; st < NS; ++st) {
         float* sin = pool + (size_t)st * 512;
         float* sout = pool + (size_t)(st + 1) * 512;
@@ -1542,6 +1560,138 @@ int rnnt_beam_select(rnnt_ctx* ctx, int32_t n_new, const int32_t* src_row_host, 
     LAUNCHCHK("beam_gather");
     HIPCHK(hipStreamSynchronize(s));   // the host arrays may be reused by the caller
     ctx->pool_cur ^= 1;
+    return RNNT_OK;
+}
+
+// Host half of one encoder frame of _decode_chunk_beam_search (model/online_rnnt_model.py:419-518) for ONE stream, pure
+// host code (also exported for CPU tests): candidates in the reference's order (per hypothesis, per evaluation: the blank
+// candidate keeping the old state, then the top-k non-blank), scores accumulated in double exactly as Python floats
+// (float32 log-prob widened, then added), stable descending sort (:506), first-wins de-duplication on the token
+// sequence (:508-516), truncation to the beam.  src_row / src_step name the pooled LSTM state each survivor keeps.
+namespace {
+struct BeamCand { std::vector<int> tokens; double score; int row, step; };
+void beam_merge_stream(const std::vector<rnnt_ctx::Hyp>& beam, int row0, const int* steps, const float* blank_lp, const float* top_lp,
+                       const int* top_tok, int n_steps, int k, int beam_size, std::vector<rnnt_ctx::Hyp>& out, std::vector<int>& src_row,
+                       std::vector<int>& src_step) {
+    std::vector<BeamCand> cands;
+    int r = row0;
+    for (const rnnt_ctx::Hyp& h : beam) {
+        std::vector<int> toks = h.tokens;
+        double lp = h.log_prob;
+        const int n = steps[r];
+        for (int st = 0; st < n; ++st) {
+            cands.push_back({toks, lp + (double)blank_lp[(size_t)r * n_steps + st], r, st});
+            for (int j = 0; j < k; ++j) {
+                BeamCand c{toks, lp + (double)top_lp[((size_t)r * n_steps + st) * k + j], r, st + 1};
+                c.tokens.push_back(top_tok[((size_t)r * n_steps + st) * k + j]);
+                cands.push_back(std::move(c));
+            }
+            if (st < n - 1) {   // chain continued with the best non-blank (:489-499)
+                toks.push_back(top_tok[((size_t)r * n_steps + st) * k]);
+                lp += (double)top_lp[((size_t)r * n_steps + st) * k];
+            }
+        }
+        ++r;
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const BeamCand& a, const BeamCand& b) { return a.score > b.score; });
+    out.clear();
+    for (BeamCand& c : cands) {
+        bool dup = false;
+        for (const rnnt_ctx::Hyp& u : out)
+            if (u.tokens == c.tokens) { dup = true; break; }
+        if (dup) continue;
+        out.push_back(rnnt_ctx::Hyp{std::move(c.tokens), c.score});
+        src_row.push_back(c.row);
+        src_step.push_back(c.step);
+        if ((int)out.size() >= beam_size) break;
+    }
+}
+}  // namespace
+
+// Pure-host export of beam_merge_stream for one stream (CPU tests; no context, no GPU).  Hypotheses are passed flat:
+// hyp_len[n_hyp], hyp_tokens (concatenated), hyp_score[n_hyp]; outputs likewise (out_tokens needs room for
+// beam_size * (longest input + n_steps) ints).  Returns the number of surviving hypotheses.
+int rnnt_beam_merge_host(int32_t n_hyp, const int32_t* hyp_len, const int32_t* hyp_tokens, const double* hyp_score, const int32_t* steps,
+                         const float* blank_lp, const float* top_lp, const int32_t* top_tok, int32_t n_steps, int32_t k, int32_t beam_size,
+                         int32_t* out_len, int32_t* out_tokens, double* out_score, int32_t* out_src_row, int32_t* out_src_step) {
+    if (n_hyp < 1 || !hyp_len || !hyp_score || !steps || !blank_lp || !top_lp || !top_tok || !out_len || !out_tokens || !out_score) return RNNT_ERR_ARG;
+    std::vector<rnnt_ctx::Hyp> beam(n_hyp), out;
+    size_t off = 0;
+    for (int i = 0; i < n_hyp; ++i) {
+        beam[i].tokens.assign(hyp_tokens + off, hyp_tokens + off + hyp_len[i]);
+        beam[i].log_prob = hyp_score[i];
+        off += hyp_len[i];
+    }
+    std::vector<int> sr, ss;
+    beam_merge_stream(beam, 0, steps, blank_lp, top_lp, top_tok, n_steps, k, beam_size, out, sr, ss);
+    off = 0;
+    for (size_t i = 0; i < out.size(); ++i) {
+        out_len[i] = (int)out[i].tokens.size();
+        for (int t : out[i].tokens) out_tokens[off++] = t;
+        out_score[i] = out[i].log_prob;
+        if (out_src_row) out_src_row[i] = sr[i];
+        if (out_src_step) out_src_step[i] = ss[i];
+    }
+    return (int)out.size();
+}
+
+// Beam search over the buffered encoder frames [frame_begin, frame_end) of every stream with the bookkeeping inside the
+// library (the reference's per-frame loop, online_rnnt_model.py:419-518, for all streams at once): per frame one
+// beam_chain launch, one copy of the candidates to the host, the merge above, one state-pool gather.
+int rnnt_beam_advance(rnnt_ctx* ctx, int32_t frame_begin, int32_t frame_end, int32_t beam_size, void* stream) {
+    if (!ctx) return RNNT_ERR_ARG;
+    if (!ctx->finalized || ctx->n_streams < 1) return fail(ctx, RNNT_ERR_STATE, "rnnt_beam_advance: no weights / no streams");
+    if (ctx->max_rows == 0) return fail(ctx, RNNT_ERR_STATE, "rnnt_beam_advance: context created with max_beam = 0");
+    if (beam_size < 1 || beam_size > ctx->cfg.max_beam) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_advance: beam_size %d outside [1, max_beam %d]", beam_size, ctx->cfg.max_beam);
+    if (frame_begin < 0 || frame_end > ctx->frames_buffered || frame_begin > frame_end) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_advance: frames [%d, %d) not buffered", frame_begin, frame_end);
+    if ((int)ctx->beams.size() != ctx->n_streams) return fail(ctx, RNNT_ERR_STATE, "rnnt_beam_advance: call rnnt_streams_reset first");
+    const int NS = ctx->cfg.n_steps, B = ctx->n_streams;
+    const int k = beam_size < ctx->cfg.vocab_size - 1 ? beam_size : ctx->cfg.vocab_size - 1;          // :467
+    std::vector<int> row_stream, row_tok, steps, top_tok, src_row, src_step;
+    std::vector<float> blank_lp, top_lp;
+    std::vector<rnnt_ctx::Hyp> next;
+    int rc;
+    for (int f = frame_begin; f < frame_end; ++f) {
+        row_stream.clear(); row_tok.clear();
+        for (int b = 0; b < B; ++b)
+            for (const rnnt_ctx::Hyp& h : ctx->beams[b]) {
+                row_stream.push_back(b);
+                row_tok.push_back(h.tokens.empty() ? ctx->cfg.blank_id : h.tokens.back());              // :429
+            }
+        const int R = (int)row_stream.size();
+        steps.resize(R); blank_lp.resize((size_t)R * NS); top_lp.resize((size_t)R * NS * k); top_tok.resize((size_t)R * NS * k);
+        if ((rc = rnnt_beam_frame(ctx, f, R, row_stream.data(), row_tok.data(), k, steps.data(), blank_lp.data(), top_lp.data(), top_tok.data(), stream)))
+            return rc;
+        src_row.clear(); src_step.clear();
+        int row0 = 0;
+        for (int b = 0; b < B; ++b) {
+            const int nh = (int)ctx->beams[b].size();
+            beam_merge_stream(ctx->beams[b], row0, steps.data(), blank_lp.data(), top_lp.data(), top_tok.data(), NS, k, beam_size, next, src_row, src_step);
+            row0 += nh;
+            ctx->beams[b].swap(next);
+        }
+        if ((rc = rnnt_beam_select(ctx, (int)src_row.size(), src_row.data(), src_step.data(), stream))) return rc;
+    }
+    return RNNT_OK;
+}
+
+// hypotheses of one stream after rnnt_beam_advance: count, then tokens / score of hypothesis i (device row = rows of the
+// earlier streams + i, the index rnnt_beam_get_states uses)
+int rnnt_beam_hyp_count(rnnt_ctx* ctx, int32_t stream_idx, int32_t* n_out) {
+    if (!ctx || !n_out || stream_idx < 0 || stream_idx >= (int)ctx->beams.size()) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_hyp_count: bad argument");
+    *n_out = (int)ctx->beams[stream_idx].size();
+    return RNNT_OK;
+}
+int rnnt_beam_get_hyp(rnnt_ctx* ctx, int32_t stream_idx, int32_t hyp_idx, int32_t cap, int32_t* tokens_host, int32_t* n_tokens, double* log_prob) {
+    if (!ctx || stream_idx < 0 || stream_idx >= (int)ctx->beams.size() || hyp_idx < 0 || hyp_idx >= (int)ctx->beams[stream_idx].size())
+        return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_get_hyp: bad index");
+    const rnnt_ctx::Hyp& h = ctx->beams[stream_idx][hyp_idx];
+    if (n_tokens) *n_tokens = (int)h.tokens.size();
+    if (log_prob) *log_prob = h.log_prob;
+    if (tokens_host) {
+        if (cap < (int)h.tokens.size()) return fail(ctx, RNNT_ERR_ARG, "rnnt_beam_get_hyp: %d tokens, room for %d", (int)h.tokens.size(), cap);
+        for (size_t i = 0; i < h.tokens.size(); ++i) tokens_host[i] = h.tokens[i];
+    }
     return RNNT_OK;
 }
 

@@ -33,6 +33,10 @@ SIGNATURES = {
     "rnnt_beam_frame": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rnnt_beam_select": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     "rnnt_beam_get_states": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "rnnt_beam_advance": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "rnnt_beam_hyp_count": (c_i32, [c_vp, c_i32, c_i32p]),
+    "rnnt_beam_get_hyp": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32p, ctypes.POINTER(ctypes.c_double)]),
+    "rnnt_beam_merge_host": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rnnt_frames_discard": (c_i32, [c_vp, c_vp]),
     "rnnt_predictor_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rnnt_joint": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -187,6 +191,23 @@ class RnntEngine:
         a = np.ascontiguousarray(src_row, np.int32)
         b = np.ascontiguousarray(src_step, np.int32)
         self._chk(self.lib.rnnt_beam_select(self.ctx, len(a), _np_ptr(a), _np_ptr(b), stream), "rnnt_beam_select")
+
+    def beam_advance(self, frame_begin, frame_end, beam_size, stream=None):
+        """Native beam search over buffered frames [frame_begin, frame_end) of every stream (bookkeeping in the library)."""
+        self._chk(self.lib.rnnt_beam_advance(self.ctx, frame_begin, frame_end, beam_size, stream), "rnnt_beam_advance")
+
+    def beam_hyps(self, b):
+        """[(tokens, log_prob), ...] of stream b in device-row order."""
+        n = c_i32(0)
+        self._chk(self.lib.rnnt_beam_hyp_count(self.ctx, b, ctypes.byref(n)), "rnnt_beam_hyp_count")
+        out = []
+        for i in range(n.value):
+            nt, lp = c_i32(0), ctypes.c_double(0.0)
+            self._chk(self.lib.rnnt_beam_get_hyp(self.ctx, b, i, 0, None, ctypes.byref(nt), ctypes.byref(lp)), "rnnt_beam_get_hyp")
+            toks = np.zeros(max(nt.value, 1), np.int32)
+            self._chk(self.lib.rnnt_beam_get_hyp(self.ctx, b, i, toks.size, _np_ptr(toks), ctypes.byref(nt), ctypes.byref(lp)), "rnnt_beam_get_hyp")
+            out.append((toks[:nt.value].tolist(), lp.value))
+        return out
 
     def beam_states(self, n_rows, stream=None):
         h, c = np.zeros((n_rows, 256), np.float32), np.zeros((n_rows, 256), np.float32)

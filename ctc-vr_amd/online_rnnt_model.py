@@ -254,11 +254,10 @@ class OnlineRNNTModel:
         x = chunk_xs.to(self.device, torch.float32).contiguous()
         s = _stream_ptr()
         tq = self._engine.encoder_chunk(x.data_ptr(), x.size(1), offset, required_cache_size, s)
-        beam = beam_hypotheses_in
-        if beam is None:
-            beam = [BeamHypothesis(tokens=[], log_prob=0.0)]                 # :407-415 (zero LSTM state = fresh pool row 0)
-        for t in range(tq):
-            beam = beam_advance_frame(self._engine, t, [beam], self.blank_id, beam_size, s)[0]
+        # The hypotheses live in the library (one empty hypothesis with the zero LSTM state after a reset, :407-415); the
+        # list handed back mirrors them, and `beam_hypotheses_in` is expected to be that list (as in the reference's callers).
+        self._engine.beam_advance(0, tq, beam_size, s)
+        beam = [BeamHypothesis(tokens=t, log_prob=lp) for t, lp in self._engine.beam_hyps(0)]
         h, c = self._engine.beam_states(len(beam), s)
         for i, hyp in enumerate(beam):
             hyp.predictor_states = [torch.from_numpy(h[i]).view(1, 1, 256).to(self.device),
@@ -363,6 +362,7 @@ class StreamingBatch:
                                  max_enc_frames=max_enc_frames, max_tokens=max_tokens, vocab_size=vocab_size, blank_id=blank_id,
                                  n_steps=10, device=device, max_beam=max_beam)
         self.beams = None
+        self.python_beam = False      # True: host half of the beam search in Python (beam_advance_frame), for tests
         self.engine.load_state_dict(state_dict)
         self.offset = 0
 
@@ -379,18 +379,41 @@ class StreamingBatch:
         s = _stream_ptr()
         tq = self.engine.encoder_chunk(chunks.data_ptr(), chunks.size(1), self.offset, self.offset, s)
         self.offset += chunks.size(1) // 4
-        if self.beams is None:
-            self.beams = [[BeamHypothesis([], 0.0)] for _ in range(self.n)]
-            # fresh streams: pool rows must be one zero-state row per stream -> rows 0..n-1 are zero after reset
-        for t in range(tq):
-            self.beams = beam_advance_frame(self.engine, t, self.beams, self.blank_id, beam_size, s)
+        if self.python_beam:                                   # reference implementation of the host half (tests)
+            if self.beams is None:
+                self.beams = [[BeamHypothesis([], 0.0)] for _ in range(self.n)]
+            for t in range(tq):
+                self.beams = beam_advance_frame(self.engine, t, self.beams, self.blank_id, beam_size, s)
+        else:                                                  # bookkeeping inside the library (rnnt_beam_advance)
+            self.engine.beam_advance(0, tq, beam_size, s)
+            self.beams = self._native_beams()
         self.engine.frames_discard(s)
         return self.beams
 
-    def beam_script(self, audios: torch.Tensor, chunk_frames: int, beam_size: int = 4):
-        """Beam loop of online_rnnt_decode.py:123-178 over [B,T,80]; returns the final beams per stream."""
+    def _native_beams(self):
+        return [[BeamHypothesis(t, lp) for t, lp in self.engine.beam_hyps(b)] for b in range(self.n)]
+
+    def beam_script(self, audios: torch.Tensor, chunk_frames: int, beam_size: int = 4, pipelined: bool = False):
+        """Beam loop of online_rnnt_decode.py:123-178 over [B,T,80]; returns the final beams per stream.
+        pipelined=True: the whole utterance's encoder in one rnnt_encoder_chunks call, then ONE rnnt_beam_advance over
+        all frames (same hypotheses: the beam recursion only consumes encoder frames in order); needs
+        max_enc_frames >= the utterance's encoder frames."""
         from .testing import chunk_plan
         self.reset()
+        if pipelined and not self.python_beam:
+            assert audios.is_cuda and audios.dtype == torch.float32 and audios.is_contiguous()
+            plan = [(a, b) for a, b in chunk_plan(audios.size(1), chunk_frames) if b - a >= 7]
+            offs, o = [], 0
+            for a, b in plan:
+                offs.append(o)
+                o += (b - a) // 4
+            s = _stream_ptr()
+            frames = self.engine.encoder_chunks(audios.data_ptr(), audios.size(1), [a for a, _ in plan], [b - a for a, b in plan], offs, offs, s, greedy=False)
+            self.offset = o
+            self.engine.beam_advance(0, frames, beam_size, s)
+            self.beams = self._native_beams()
+            self.engine.frames_discard(s)
+            return self.beams
         for (a, b) in chunk_plan(audios.size(1), chunk_frames):
             self.process_chunk_beam(audios[:, a:b, :].contiguous(), beam_size)
         return self.beams

@@ -134,6 +134,23 @@ int rnnt_beam_frame(rnnt_ctx* ctx, int32_t frame_idx, int32_t n_rows, const int3
 int rnnt_beam_select(rnnt_ctx* ctx, int32_t n_new, const int32_t* src_row_host, const int32_t* src_step_host, void* stream);
 /* current [h,c] of rows 0..n_rows-1: h_host, c_host [n_rows,256].  Synchronises. */
 int rnnt_beam_get_states(rnnt_ctx* ctx, int32_t n_rows, float* h_host, float* c_host, void* stream);
+
+/* Beam search with the bookkeeping inside the library: the per-frame loop of _decode_chunk_beam_search
+ * (model/online_rnnt_model.py:419-518) over the buffered frames [frame_begin, frame_end) of every stream -- extension
+ * chains on the device (one resident workgroup per hypothesis), candidate order / double-precision scores / stable
+ * sort / first-wins de-duplication on the host in C++, state pool gather.  rnnt_streams_reset starts every stream with
+ * one empty hypothesis (:407-415).  Results: rnnt_beam_hyp_count / rnnt_beam_get_hyp (tokens_host may be NULL to query
+ * the length); hypothesis i of stream b is device row (hypotheses of streams < b) + i for rnnt_beam_get_states. */
+int rnnt_beam_advance(rnnt_ctx* ctx, int32_t frame_begin, int32_t frame_end, int32_t beam_size, void* stream);
+int rnnt_beam_hyp_count(rnnt_ctx* ctx, int32_t stream_idx, int32_t* n_out);
+int rnnt_beam_get_hyp(rnnt_ctx* ctx, int32_t stream_idx, int32_t hyp_idx, int32_t cap, int32_t* tokens_host, int32_t* n_tokens,
+                      double* log_prob);
+/* The host half of one frame for one stream as a pure function (no context, no GPU; CPU tests): flat hypotheses in,
+ * flat survivors out, returns their number.  Same code rnnt_beam_advance runs. */
+int rnnt_beam_merge_host(int32_t n_hyp, const int32_t* hyp_len, const int32_t* hyp_tokens, const double* hyp_score,
+                         const int32_t* steps, const float* blank_lp, const float* top_lp, const int32_t* top_tok,
+                         int32_t n_steps, int32_t k, int32_t beam_size, int32_t* out_len, int32_t* out_tokens,
+                         double* out_score, int32_t* out_src_row, int32_t* out_src_step);
 /* drop all buffered encoder frames (beam path; the greedy path uses rnnt_frames_consume). */
 int rnnt_frames_discard(rnnt_ctx* ctx, void* stream);
 

@@ -79,3 +79,60 @@ def test_host_beam_logic_matches_reference(name, np_state_dict):
         for hi, h in enumerate(beam):
             assert h.tokens == g[f"c{ci}_h{hi}_tokens"].tolist(), (ci, hi)
             assert abs(h.log_prob - float(g[f"c{ci}_h{hi}_logp"])) < 1e-3
+
+
+def test_native_beam_merge_equals_python_host_logic():
+    """rnnt_beam_merge_host (the C++ merge rnnt_beam_advance runs; pure host code, loadable without a GPU) against the
+    Python host logic above on seeded random extension tables: identical survivors, scores bit-equal as doubles,
+    identical state-slot selection -- including ties (coarse score grid) and duplicate token sequences."""
+    import ctypes
+    from ctc_vr_amd import lib as L
+    lib = L.load()
+    rng = np.random.default_rng(11)
+    ns = 10
+    for case in range(60):
+        k = int(rng.integers(1, 5))
+        beam_size = int(rng.integers(1, 6))
+        n_hyp = int(rng.integers(1, 5))
+        hyps = []
+        seen = set()
+        while len(hyps) < n_hyp:
+            toks = rng.integers(0, 4, int(rng.integers(0, 4))).tolist()
+            if tuple(toks) not in seen:
+                seen.add(tuple(toks))
+                hyps.append(BeamHypothesis(toks, float(np.round(rng.normal(-3, 2), 1))))
+        steps = rng.integers(1, ns + 1, n_hyp).astype(np.int32)
+        grid = 4.0 if case % 2 else 1000.0                                    # coarse grid: many exact ties
+        blank_lp = (np.round(rng.normal(-2, 1.5, (n_hyp, ns)) * grid) / grid).astype(np.float32)
+        top_lp = (np.round(rng.normal(-3, 1.5, (n_hyp, ns, k)) * grid) / grid).astype(np.float32)
+        top_tok = rng.integers(0, 4, (n_hyp, ns, k)).astype(np.int32)
+
+        class Tab:
+            class cfg:
+                vocab_size = 100
+            sel = None
+
+            def beam_frame(self, frame_idx, row_stream, row_tok, kk, stream=None):
+                return steps, blank_lp, top_lp, top_tok
+
+            def beam_select(self, src_row, src_step, stream=None):
+                self.sel = (list(src_row), list(src_step))
+        # the Python logic derives k from beam_size; feed it the same k through beam_size == k
+        eng2 = Tab()
+        want = beam_advance_frame(eng2, 0, [[h.copy() for h in hyps]], 99, k)[0]
+        hyp_len = np.array([len(h.tokens) for h in hyps], np.int32)
+        hyp_tok = np.array([t for h in hyps for t in h.tokens] + [0], np.int32)
+        hyp_score = np.array([h.log_prob for h in hyps], np.float64)
+        cap = k * (int(hyp_len.max(initial=0)) + ns + 1) + 8
+        out_len, out_tok = np.zeros(k, np.int32), np.zeros(cap, np.int32)
+        out_score, out_row, out_step = np.zeros(k, np.float64), np.zeros(k, np.int32), np.zeros(k, np.int32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        n = lib.rnnt_beam_merge_host(n_hyp, p(hyp_len), p(hyp_tok), p(hyp_score), p(steps), p(blank_lp), p(top_lp), p(top_tok), ns, k, k,
+                                     p(out_len), p(out_tok), p(out_score), p(out_row), p(out_step))
+        assert n == len(want), case
+        off = 0
+        for i, h in enumerate(want):
+            assert out_tok[off:off + out_len[i]].tolist() == h.tokens, (case, i)
+            assert out_score[i] == h.log_prob, (case, i)
+            off += out_len[i]
+        assert (out_row[:n].tolist(), out_step[:n].tolist()) == eng2.sel, case

@@ -176,6 +176,32 @@ def test_batched_beam_equals_single_stream(np_state_dict):
         assert [h.tokens for h in beams[b]] == [g[f"c{last}_h{i}_tokens"].tolist() for i in range(int(g[f"c{last}_n"]))]
 
 
+def test_native_beam_paths(np_state_dict, monkeypatch):
+    """The beam search with the bookkeeping in the library (rnnt_beam_advance: beam_chain kernel + C++ merge) against
+    the Python host logic over the same device calls (hypotheses and double scores identical), the whole-utterance form
+    (one encoder call + one rnnt_beam_advance) against the per-chunk loop, and the launched extension steps
+    (RNNT_BEAM_CHAIN=0) against the chain kernel (same tokens; scores differ by float32 summation order)."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    syn = torch.from_numpy(T.synth_fbank(3, 320, seed=21)).cuda().contiguous()
+    mk = lambda: StreamingBatch(np_state_dict(1), 3, max_chunk_frames=32, max_cache_frames=128, max_enc_frames=128, max_beam=4)
+    sb = mk()
+    native = sb.beam_script(syn, 16, 4)
+    sb.python_beam = True
+    python = sb.beam_script(syn, 16, 4)
+    sb.python_beam = False
+    piped = sb.beam_script(syn, 16, 4, pipelined=True)
+    for b in range(3):
+        assert [h.tokens for h in native[b]] == [h.tokens for h in python[b]], b
+        assert [h.log_prob for h in native[b]] == [h.log_prob for h in python[b]], b
+        assert [h.tokens for h in piped[b]] == [h.tokens for h in native[b]], b
+        assert max(abs(x.log_prob - y.log_prob) for x, y in zip(piped[b], native[b])) < 1e-3, b
+    monkeypatch.setenv("RNNT_BEAM_CHAIN", "0")
+    launched = mk().beam_script(syn, 16, 4)
+    for b in range(3):
+        assert launched[b][0].tokens == native[b][0].tokens, b
+        assert abs(launched[b][0].log_prob - native[b][0].log_prob) < 1e-3, b
+
+
 def test_enc_out_full_trace(models):
     g = load_golden("stream_syn0_c16_s0.npz")
     from ctc_vr_amd.online_rnnt_model import StreamingBatch  # noqa: F401
