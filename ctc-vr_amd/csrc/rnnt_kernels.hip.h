@@ -2247,12 +2247,35 @@ __global__ void beam_gather(const float* __restrict__ old_pool, float* __restric
     for (int i = threadIdx.x; i < 512; i += blockDim.x) d[i] = s[i];
 }
 
-// log_softmax over the last dimension, in place, one wave per row (joint lattice mode 1).
-__global__ void log_softmax_rows(float* __restrict__ x, long long rows, int n) {
+// log_softmax over the last dimension, in place, one wave per row (joint lattice mode 1).  A row (n <= 512 floats) is read
+// ONCE into registers (8 values per lane), reduced, and written once: the pass is a pure HBM stream of 2 x rows x n x 4 B.
+// Rows longer than 512 take the three-pass loop.
+__global__ __launch_bounds__(256) void log_softmax_rows(float* __restrict__ x, long long rows, int n) {
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     float* p = x + row * n;
+    if (n <= 512) {
+        float v[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = lane + 64 * j;
+            v[j] = idx < n ? ldg1(p + idx) : -INFINITY;
+            mx = fmaxf(mx, v[j]);
+        }
+        mx = wave_max(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) se += (lane + 64 * j) < n ? expf(v[j] - mx) : 0.f;
+        const float lse = logf(wave_sum(se));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < n) stg1(p + idx, v[j] - mx - lse);
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int v = lane; v < n; v += 64) mx = fmaxf(mx, p[v]);
     mx = wave_max(mx);
