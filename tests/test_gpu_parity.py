@@ -403,6 +403,36 @@ def test_offline_greedy_search_matches_reference(seed, np_state_dict):
     assert a is None and b is None and [len(h) for h in hyps] == g["counts_n64"].tolist()
 
 
+def test_wav_to_tokens_cli_flow(tmp_path, np_state_dict):
+    """online_rnnt_decode.py's flow end to end: PCM wav -> device features -> chunk loop (greedy + beam) from a
+    checkpoint file; the greedy tokens equal the oracle run on the same features, the beam's best path is reported
+    incrementally as in the reference (:148)."""
+    import wave
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_decode import decode_single_audio, chunk_bounds
+    rate, n = 16000, 16000 * 8                                   # 8 s -> 251 feature frames (hop 512)
+    rng = np.random.default_rng(3)
+    t = np.arange(n) / rate
+    sig = 0.3 * np.sin(2 * np.pi * (300 + 200 * np.sin(2 * np.pi * 0.7 * t)) * t) + 0.05 * rng.standard_normal(n)
+    pcm = np.clip(sig * 32768, -32768, 32767).astype("<i2")
+    wav = tmp_path / "a.wav"
+    with wave.open(str(wav), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(rate); f.writeframes(pcm.tobytes())
+    sd_np = np_state_dict(0)
+    ckpt = tmp_path / "online_model.pt"
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in sd_np.items()}, "epoch": 4}, str(ckpt))
+    res = decode_single_audio(str(wav), str(ckpt), vocab_size=T.VOCAB, blank_id=T.BLANK, static_chunk_size=32, beam_size=4, verbose=False,
+                              predictor_dropout=0)
+    assert chunk_bounds(251, 32)[-1] == (192, 251) and res["chunks"] == 7
+    from ctc_vr_amd.online_rnnt_model import OnlineRNNTModel
+    m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=T.VOCAB, blank_id=T.BLANK, streaming=True, static_chunk_size=32)
+    feats = m.extract_audio_features(torch.from_numpy(pcm.astype(np.float32) / 32768.0), rate).cpu()
+    want, _, _ = O.decode_script_greedy(O.to_torch_sd(sd_np), feats[None], 32)
+    assert res["greedy_tokens"] == want
+    best = max(res["beam_hypotheses"], key=lambda h: h.log_prob)
+    assert res["beam_tokens"][:len(best.tokens)] == res["beam_tokens"] and len(res["beam_tokens"]) >= 1
+
+
 def test_rtf_harness(models):
     """per-chunk RTF statistics with online_rnnt_delay.py's definition."""
     from ctc_vr_amd.online_rnnt_delay import evaluate_rtf
