@@ -1936,6 +1936,15 @@ int rnnt_fbank(rnnt_ctx* ctx, const float* wave_dev, int32_t B, int32_t n_sample
     return RNNT_OK;
 }
 
+// diagnostic only (not in the header): n_bytes streamed src -> dst `iters` times with the given cache policy
+int rnnt_debug_stream_copy(rnnt_ctx* ctx, const float* src_dev, float* dst_dev, int64_t n_bytes, int32_t mode, int32_t iters, void* stream) {
+    if (!ctx || !src_dev || !dst_dev) return RNNT_ERR_ARG;
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(debug_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev, (long long)(n_bytes / 16), mode);
+    LAUNCHCHK("debug_stream_copy");
+    return RNNT_OK;
+}
+
 int rnnt_get_att_cache(rnnt_ctx* ctx, int32_t b, float* dst_host, int32_t* len_out, void* stream) {
     if (!ctx || b < 0 || b >= ctx->n_streams) return fail(ctx, RNNT_ERR_ARG, "rnnt_get_att_cache: bad stream index");
     hipStream_t s = (hipStream_t)stream;

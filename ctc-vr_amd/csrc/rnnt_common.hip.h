@@ -116,6 +116,7 @@ __device__ __forceinline__ int ldgi(const int* p) { return *(const RNNT_GAS int*
 __device__ __forceinline__ void stg1(float* p, float v) { *(RNNT_GAS float*)p = v; }
 __device__ __forceinline__ void stg1_nt(float* p, float v) { __builtin_nontemporal_store(v, (RNNT_GAS float*)p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *(RNNT_GAS f32x4g*)p = (f32x4g){v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void stg4_nt(float* p, float4 v) { __builtin_nontemporal_store((f32x4g){v.x, v.y, v.z, v.w}, (RNNT_GAS f32x4g*)p); }
 #else   // host pass of the single-source compile: never executed
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ldg4_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -124,6 +125,7 @@ __device__ __forceinline__ int ldgi(const int* p) { return *p; }
 __device__ __forceinline__ void stg1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stg1_nt(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stg4_nt(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 #endif
 
 __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic, int shift) {   // exact for 0 <= n < 2^31

@@ -51,3 +51,13 @@ __global__ void gather_cnn_cache(const float* __restrict__ xring, const float* _
     d[(lane * 4 + 2) * RNNT_LORDER + i] = o.z;
     d[(lane * 4 + 3) * RNNT_LORDER + i] = o.w;
 }
+
+// Diagnostic (tools/decoder_contention.py): a plain streaming copy with selectable cache policy, to see what a streaming
+// neighbour does to the resident decoder.  mode 0: default loads/stores, 1: non-temporal loads, 2: non-temporal loads and stores.
+__global__ void debug_stream_copy(const float* __restrict__ src, float* __restrict__ dst, long long n4, int mode) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = mode >= 1 ? ldg4_nt(src + 4 * i) : ldg4(src + 4 * i);
+        if (mode >= 2) stg4_nt(dst + 4 * i, v);
+        else stg4(dst + 4 * i, v);
+    }
+}
