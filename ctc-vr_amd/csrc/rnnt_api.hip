@@ -1181,7 +1181,8 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     std::vector<hipEvent_t> slab_ev(C, nullptr);           // set on the first chunk of every slab
     for (int c0 = 0; c0 < C;) {
         int c1 = c0 + 1;
-        while (c1 < C && ci[c1].len == ci[c0].len && c1 - c0 < ctx->wf_slab) ++c1;
+        const int slab = (c0 == 0 && ss != s) ? (ctx->wf_slab < 4 ? ctx->wf_slab : 4) : ctx->wf_slab;   // a short first slab: stage 0 starts sooner
+        while (c1 < C && ci[c1].len == ci[c0].len && c1 - c0 < slab) ++c1;
         if ((rc = run_subsample(ctx, ss, fbank_dev, B, total_frames, ci[c0].len, ctx->wf_starts + c0, c1 - c0, ctx->wf_y1, ctx->wf_y2,
                                 ctx->wf_x + ci[c0].xoff * D)))
             return rc;
