@@ -99,6 +99,11 @@ struct rnnt_ctx {
     hipStream_t sub_stream = nullptr;          // subsampling slabs
     int wf_groups = 2, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4), RNNT_WF_SUB_ASYNC
     int wf_merge = 2;                          // RNNT_WF_MERGE (1..WF_MERGE_MAX): chunks of one layer per wavefront stage
+    // descriptor tables of the last rnnt_encoder_chunks call, reused when the next call has the same plan and entry state
+    struct WfLaunch { int type, off, n, maxM, maxT2; };   // type 0..7 gemm (ffn1m ffn2m qkv out pw1 pw2 ffn1 ffn2), 10 attn, 11 dw, 12 ln
+    std::vector<WfLaunch> wf_seq;
+    std::vector<std::array<int, 13>> wf_lstart;
+    std::vector<int> wf_sc_first, wf_key;
     std::vector<hipEvent_t> ev_pool;
     // native beam bookkeeping (rnnt_beam_advance): per stream, hypotheses in device-row order
     struct Hyp { std::vector<int> tokens; double log_prob; };
@@ -815,6 +820,7 @@ int rnnt_finalize_weights(rnnt_ctx* ctx, int32_t numerics_mode, void* stream) {
     if (numerics_mode != RNNT_NUMERICS_FP32) return fail(ctx, RNNT_ERR_ARG, "unsupported numerics mode %d", numerics_mode);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ctx->cfg.device));
+    ctx->wf_key.clear();   // cached descriptor tables point into the weight blob
     const int V = ctx->cfg.vocab_size;
     std::vector<float> blob;
     std::vector<std::pair<const float**, size_t>> fix;   // pointer slots to patch with blob offsets
@@ -1192,10 +1198,20 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
         }
         c0 = c1;
     }
+    using Launch = rnnt_ctx::WfLaunch;
+    const auto t_tab0 = std::chrono::steady_clock::now();
+    const int KM = ctx->wf_merge;
+    std::vector<int> key = {B, C, KM, total_frames, ctx->cache_len, ctx->kv_start, ctx->conv_pos, ctx->frames_buffered};
+    key.insert(key.end(), chunk_start, chunk_start + C); key.insert(key.end(), chunk_len, chunk_len + C);
+    key.insert(key.end(), offsets, offsets + C); key.insert(key.end(), required, required + C);
+    std::vector<rnnt_ctx::WfLaunch>& seq = ctx->wf_seq;
+    std::vector<std::array<int, 13>>& lstart = ctx->wf_lstart;
+    std::vector<int>& sc_first = ctx->wf_sc_first;
+    if (key != ctx->wf_key) {                                // same plan from the same state: the device tables are still valid
+    seq.clear(); sc_first.clear();
+    ctx->wf_key.clear();
     // ---- (b) wavefront tables ---------------------------------------------------------------------------------
-    struct Launch { int type, off, n, maxM, maxT2; };   // type 0..9 gemm (ffn1m ffn2m qkv out pw1 pw2 ffn1 ffn2), 10 attn, 11 dw, 12 ln
     std::vector<GemmP> gt; std::vector<AttnP> at; std::vector<DwP> dt; std::vector<LnP> lt;
-    std::vector<Launch> seq;
     gt.reserve((size_t)C * L * 12); at.reserve((size_t)C * L); dt.reserve((size_t)C * L); lt.reserve((size_t)C * (L + 1));
     // Stage of pair (chunk c, layer l) = c / KM + l: KM consecutive chunks of a layer share a stage.  Everything but
     // attention and the depthwise conv is per-frame, and those two only need the SAME layer's K/V rows / ring rows of the
@@ -1204,18 +1220,16 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     // A chunk joins its predecessor's stage only if the K/V rows it appends lie behind everything the predecessor reads or
     // writes (the reference re-bases the cache at row 0 after the first chunk, whose K/V are dropped: chunk 1 would overwrite
     // chunk 0's rows inside one launch).
-    const int KM = ctx->wf_merge;
-    std::vector<int> sc_first;                               // first chunk of every super-chunk (+ C)
     for (int c = 0, cnt = 0; c < C; ++c) {
         const bool behind = c > 0 && ci[c].kv_row0 + ci[c].T2 - ci[c].tq >= ci[c - 1].kv_row0 + ci[c - 1].T2;
         if (c == 0 || cnt == KM || !behind) { sc_first.push_back(c); cnt = 0; }
         ++cnt;
     }
-    const int NSC = (int)sc_first.size();                    // super-chunks
     sc_first.push_back(C);
+    const int NSC = (int)sc_first.size() - 1;                // super-chunks
     const int NS = NSC + L - 1;                              // stages
     std::vector<LayerDescs> cur;
-    std::vector<std::array<int, 13>> lstart((size_t)NS);     // per stage: first pair index of every layer (+ total)
+    lstart.assign((size_t)NS, std::array<int, 13>());       // per stage: first pair index of every layer (+ total)
     for (int st = 0; st < NS; ++st) {
         cur.clear();
         int maxM = 0, maxtq = 0, maxT2 = 0;
@@ -1269,6 +1283,11 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
     HIPCHK(hipMemcpyAsync(ctx->wf_dtab, dt.data(), dt.size() * sizeof(DwP), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->wf_ltab, lt.data(), lt.size() * sizeof(LnP), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // the host vectors die at return; tables are small (a few MB)
+    if (getenv("RNNT_TIMING")) fprintf(stderr, "[rnnt timing] descriptor tables: %.3f ms on the host (%zu GEMM descriptors)\n",
+                                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tab0).count(), gt.size());
+    ctx->wf_key = key;
+    }
+    const int NSC = (int)sc_first.size() - 1, NS = NSC + L - 1;   // super-chunks, stages
     static const int gN[8] = {FF, D, D, D, 2 * D, D, FF, D};
     static const int gK[8] = {D, FF, D, D, D, D, D, FF};
     static const int gTag[8] = {TAG_FFN1, TAG_FFN2, TAG_QKV, TAG_ATTN_OUT, TAG_PW1, TAG_PW2, TAG_FFN1, TAG_FFN2};
