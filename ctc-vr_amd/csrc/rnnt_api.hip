@@ -1355,9 +1355,11 @@ int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_fra
                     if ((rc = launch_gemm_tab(ctx, x, ctx->wf_gtab + q.off + mult * p0, mult * pn, q.maxM, gN[q.type], gK[q.type], gTag[q.type]))) return rc;
                 } else if (q.type == 10) {
                     ProfScope prof(ctx, x, TAG_ATTN);
+                    static const int attn_pair_major = getenv("RNNT_ATTN_PAIR_MAJOR") ? atoi(getenv("RNNT_ATTN_PAIR_MAJOR")) : 1;
                     if (attn_stream_ok(ctx, q.maxM, q.maxT2 > 0 ? q.maxT2 : 1)) {
                         const int cap = attn_t2cap(q.maxT2);
-                        hipLaunchKernelGGL(rel_attention_stream_tab, dim3(B * RNNT_H, 1, pn), dim3(256), attn_stream_lds(cap), x, ctx->wf_atab + q.off + p0, cap);
+                        hipLaunchKernelGGL(rel_attention_stream_tab, dim3((B * RNNT_H + 7) / 8 * 8 * pn), dim3(256), attn_stream_lds(cap), x,
+                                           ctx->wf_atab + q.off + p0, cap, pn, B * RNNT_H, attn_pair_major);
                         LAUNCHCHK("rel_attention_stream_tab");
                         continue;
                     }

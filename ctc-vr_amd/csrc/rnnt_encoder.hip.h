@@ -234,14 +234,14 @@ __global__ __launch_bounds__(256) void rel_attention_tab(const AttnP* __restrict
 // One workgroup per (stream, head); LDS = 4 score rows + 16 KB of partial sums, so 8 workgroups fit a CU and their
 // phases interleave.  Dynamic LDS: (4 * t2cap + 16 * 4 * 64) floats.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rel_attention_stream_body(const AttnP& P, float* smem, int t2cap) {
+__device__ __forceinline__ void rel_attention_stream_body(const AttnP& P, float* smem, int t2cap, int bh) {
     const float* __restrict__ kc = P.kc;
     const float* __restrict__ vc = P.vc;
     const int tq = P.tq, T2 = P.T2;
     float* S = smem;                       // [4][t2cap] scores, then probabilities
     float* red = smem + 4 * t2cap;         // [16 groups][4 queries][64]
     __shared__ float linv[4];
-    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
+    const int b = bh / RNNT_H, h = bh % RNNT_H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = tid >> 4, l16 = tid & 15;
     const int nk = P.klen ? min(ldgi(P.klen + b), T2) : T2;
@@ -348,12 +348,22 @@ __device__ __forceinline__ void rel_attention_stream_body(const AttnP& P, float*
 }
 __global__ __launch_bounds__(256) void rel_attention_stream(AttnP p, int t2cap) {
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
-    rel_attention_stream_body(p, att_smem, t2cap);
+    rel_attention_stream_body(p, att_smem, t2cap, blockIdx.x);
 }
-__global__ __launch_bounds__(256) void rel_attention_stream_tab(const AttnP* __restrict__ tab, int t2cap) {
+// Table form, 1-D grid of ceil(bh_total / 8) * 8 * n_desc workgroups dealt round-robin over the 8 XCDs: XCD x takes the
+// (stream, head) pairs x, x + 8, ... and runs ALL descriptors of a pair back to back.  With two chunks of a layer per
+// stage the second chunk reads the K/V rows the first one has just pulled into that XCD's L2 (its own three rows more),
+// so the cache is streamed from HBM once per stage instead of once per chunk.  Placement is a speed hint only.
+__global__ __launch_bounds__(256) void rel_attention_stream_tab(const AttnP* __restrict__ tab, int t2cap, int n_desc, int bh_total, int pair_major) {
     extern __shared__ __attribute__((aligned(16))) float att_smem[];
-    const AttnP p = tab[blockIdx.z];
-    rel_attention_stream_body(p, att_smem, t2cap);
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int per = (bh_total + 7) / 8;                        // (stream, head) pairs per XCD
+    const int d = pair_major ? slot % n_desc : slot / per;
+    const int bh = (pair_major ? slot / n_desc : slot % per) * 8 + xcd;
+    if (bh >= bh_total || d >= n_desc) return;
+    const AttnP p = tab[d];
+    rel_attention_stream_body(p, att_smem, t2cap, bh);
 }
 
 // ------------------------------------------------------------------------------------------------
