@@ -304,6 +304,26 @@ def main():
         roofline["launches_timed"] = int(site_launches)
         roofline["share_of_step"] = round(site_ms * 1e-3 / elapsed, 4)
 
+    # The other launch sites, two extra passes each in the same overlapped pipeline (outside the timed region): the FFN and
+    # projection GEMMs together take more of the step than conv2 does, at a lower fraction of the peak.
+    other_sites = None
+    if roofline is not None and world == 1 and args.mode == "pipelined" and args.site == "conv2":
+        other_sites = {}
+        for site in ("ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "attn", "dwconv"):
+            sb.engine.profile_begin(TAGS[site])
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ms, nl = sb.engine.profile_end()
+            f2, b2, _ = site_flops_bytes(site, B, plan)
+            if nl > 0:
+                hbm2 = site in ("attn", "dwconv")
+                ach2 = (b2 if hbm2 else f2) * 2 / (ms * 1e-3) / (1e9 if hbm2 else 1e12)
+                pk = PEAK_HBM_GBS if hbm2 else PEAK_F32_MFMA_TFLOPS
+                other_sites[site] = {"kernel": SITE_KERNEL.get(site, site), "bound": "hbm" if hbm2 else "mfma", "achieved": round(ach2, 2),
+                                     "unit": "GB/s" if hbm2 else "TFLOP/s", "frac": round(ach2 / pk, 4), "avg_launch_us": round(ms * 1e3 / nl, 2),
+                                     "ms_per_step": round(ms / 2, 3)}
+
     # The same kernel with nothing else on the device: in the timed region the subsampling stream runs UNDER the encoder
     # stages and next to the resident decoder, which is good for the step time and bad for this one kernel's duration.
     # A second context with the overlaps switched off times it alone (same inputs, same launches, outside the timed region).
@@ -394,6 +414,7 @@ def main():
         "weight_broadcast_ms": round(bcast_ms, 3),
         "roofline": roofline,
         "roofline_isolated": roofline_isolated,
+        "roofline_other_sites": other_sites,
         "cpu_baseline": cpu,
         "per_chunk_api": per_chunk_extra,
     }
