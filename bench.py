@@ -328,6 +328,7 @@ def main():
     # stages and next to the resident decoder, which is good for the step time and bad for this one kernel's duration.
     # A second context with the overlaps switched off times it alone (same inputs, same launches, outside the timed region).
     roofline_isolated = None
+    encoder_only = None
     if roofline is not None and world == 1 and args.mode == "pipelined":
         saved = {k: os.environ.get(k) for k in ("RNNT_WF_SUB_ASYNC", "RNNT_WF_GROUPS")}
         os.environ["RNNT_WF_SUB_ASYNC"] = "0"
@@ -348,10 +349,17 @@ def main():
         enc_only()
         torch.cuda.synchronize()
         sb2.engine.profile_begin(TAGS[args.site])
+        t_iso = time.perf_counter()
         for _ in range(2):
             enc_only()
         torch.cuda.synchronize()
+        t_iso = (time.perf_counter() - t_iso) / 2
         iso_ms, iso_n = sb2.engine.profile_end()
+        # the whole encoder (no decoder, one stream): all dense contractions + attention, algorithmic FLOPs of SURVEY.md §8d
+        enc_flops = sum(site_flops_bytes(k, B, plan)[0] for k in ("conv2", "embed", "ffn1", "ffn2", "qkv", "attn", "attn_out", "pw1", "dwconv", "pw2"))
+        encoder_only = {"ms": round(t_iso * 1e3, 3), "algorithmic_tflop": round(enc_flops / 1e12, 4), "achieved": round(enc_flops / t_iso / 1e12, 2),
+                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(enc_flops / t_iso / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                        "note": "whole chunked encoder of the batch, single stream, no decoder; wall clock around rnnt_encoder_chunks"}
         if iso_n > 0:
             hbm = roofline["bound"] == "hbm"
             ach = (by if hbm else fl) * 2 / (iso_ms * 1e-3) / (1e9 if hbm else 1e12)
@@ -415,6 +423,7 @@ def main():
         "roofline": roofline,
         "roofline_isolated": roofline_isolated,
         "roofline_other_sites": other_sites,
+        "encoder_only": encoder_only,
         "cpu_baseline": cpu,
         "per_chunk_api": per_chunk_extra,
     }
