@@ -308,6 +308,18 @@ def test_alternative_decoder_paths(np_state_dict, env, monkeypatch):
             assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (env, mode, i)
 
 
+def test_long_utterance_pipelined_equals_per_chunk(np_state_dict):
+    """30 s utterances (562 cached keys per layer at the end, 186 chunks: many wavefront stages, streaming attention over
+    several 64-key rounds, tail-merged last chunk): whole-utterance call == per-chunk API, for two chunk sizes."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    sb = StreamingBatch(np_state_dict(1), 4, max_chunk_frames=64, max_cache_frames=800, max_enc_frames=800, max_tokens=8000)
+    x = torch.from_numpy(T.synth_fbank(4, 3000, seed=9)).cuda().contiguous()
+    for chunk in (16, 32):
+        a = sb.decode_script(x, chunk, pipelined=True)
+        assert a == sb.decode_script(x, chunk, per_chunk_decode=True), chunk
+        assert min(len(t) for t in a) > 0
+
+
 def test_fresh_inputs_against_oracle(np_state_dict):
     """Seeded inputs no fixture covers: HIP (B=4, chunk 24) vs the CPU oracle run stream by stream."""
     from oracle import rnnt_oracle as O
