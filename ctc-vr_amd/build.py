@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rnnt_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "rnnt_kernels.hip.h"), os.path.join(os.path.dirname(HERE), "include", "rnnt_hip.h")]
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))) + [os.path.join(os.path.dirname(HERE), "include", "rnnt_hip.h")]
 LIB = os.path.join(HERE, "librnnt_hip.so")
 
 
