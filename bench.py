@@ -214,6 +214,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a one-GPU box: BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
@@ -221,7 +226,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     # ---- weights: generated on rank 0, ONE RCCL broadcast of the packed blob over xGMI --------------------
     import ctc_vr_amd.dist as D
