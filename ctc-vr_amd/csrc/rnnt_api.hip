@@ -47,6 +47,7 @@ struct rnnt_ctx {
     // packed weights (one device blob)
     float* blob = nullptr;
     size_t blob_floats = 0;
+    unsigned short *blob_hi = nullptr, *blob_lo = nullptr;   // 16-bit hi / lo planes of the blob (split-operand numerics modes)
     LayerW lw[L];
     const float *conv1_wt, *conv1_b, *conv2_w, *conv2_b, *emb_w, *emb_b, *pe, *after_g, *after_b;
     const float *ln_conv_g_all, *ln_conv_b_all, *glu0;

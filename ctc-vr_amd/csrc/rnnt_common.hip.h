@@ -1,11 +1,14 @@
-// Device kernels of the gfx950 streaming RNN-T path.  fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32: bit-for-bit a
-// k-ordered fmaf chain) so that greedy tokens can match the reference's float32 CPU path.
+// Device kernels of the gfx950 streaming RNN-T path.  fp32 storage.  Numerics modes (rnnt_finalize_weights): exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf chain, the default parity mode) or 16-bit split-operand MFMA for the
+// dense contractions (bf16x3, f16x3: ~1e-5 / ~1e-6 relative, parity-gated; plain bf16: perf mode, token-match rate reported).
 //
 // Kernel inventory by header (DESIGN.md §5 has the roofline per kernel):
 //   rnnt_common    epilogue kinds, GemmP descriptor (generalised A / C addressing: implicit-GEMM conv2, K/V-cache append,
 //                  ring buffers, implicit STFT frames), address-space-1 load/store helpers, wave reductions
 //   rnnt_gemm      gemm16 (16-row tiles, split-K, LSTM-cell / fused-argmax epilogues), gemm_ns / gemm_ns_tab (LDS-tiled
-//                  grouped GEMM, LayerNorm prologue, XCD-aware mapping), gemm32 (first generation)
+//                  grouped GEMM, LayerNorm prologue, XCD-aware mapping) -- exact f32 (v_mfma_f32_16x16x4_f32)
+//   rnnt_gemm_bf   gemm_bf / gemm_bf_tab: the same GEMM contract on v_mfma_f32_16x16x32_{bf16,f16} with split operands
+//                  (bf16x3 / f16x3: hi*hi + hi*lo + lo*hi, f32 accumulate; bf16: hi*hi), joint_lattice_fused
 //   rnnt_encoder   conv1_relu, layer_norm, rel_attention (LDS tiles, online softmax), rel_attention_stream (<= 4 queries,
 //                  direct row streaming), dwconv_bn_silu, conv_ring_init
 //   rnnt_decode    greedy_decide (launched path), greedy_stream (resident decoder), greedy_flow (cooperative experiment),
@@ -87,7 +90,9 @@ struct GemmP {
     int a_tanh;                  // gemm_ns A prologue: a = tanh(A[row(m)][k] + X[(m / x_n) * x_s0 + k]) (joint lattice, joint.py:60-66)
     const int* act_idx;          // greedy decode: row m is active iff act_idx[m] < *act_lim; a workgroup whose rows are
     const int* act_lim;          //   all idle exits at once (idle budgeted steps must cost nothing); null = always active
-    int dbg;       // microbenchmark ablation bits (0 in production): 1 skip global loads, 2 skip MFMAs, 4 skip epilogue
+    // 16-bit operand planes of W (rnnt_gemm_bf.hip.h): same element index as W inside the weight blob; null = exact f32 only
+    const unsigned short* Wh;
+    const unsigned short* Wl;
     unsigned a_n1_magic, a_n2_magic, a_seg_magic, c_n_magic, x_n_magic;
     int a_n1_shift, a_n2_shift, a_seg_shift, c_n_shift, x_n_shift;   // q = umulhi(n, magic) >> shift, exact for n < 2^31
 };

@@ -1,181 +1,7 @@
-// GEMM kernels: gemm32 (first generation), gemm16 (16-row tiles, split-K), gemm_ns / gemm_ns_tab (LDS-tiled, grouped).
+// GEMM kernels (exact f32): gemm16 (16-row tiles, split-K), gemm_ns / gemm_ns_tab (LDS-tiled, grouped).
+// The 16-bit split-operand family (bf16x3 / bf16 / f16x3) lives in rnnt_gemm_bf.hip.h and shares ns_epilogue below.
 // Part of rnnt_kernels.hip.h (include that umbrella, not this file).
 #pragma once
-
-// ------------------------------------------------------------------------------------------------
-// gemm32<WK>: C[32x32 tile] = epi(A[M,K] * W[N,K]^T).  grid = (ceil(N/32), ceil(M/32), groups),
-// block = 64*WK threads.  Wave w accumulates K-slice [w*K/WK, (w+1)*K/WK) with 32x32x2 f32 MFMAs:
-// lane (i = l&31, kh = l>>5) feeds A[m0+i][k + 4*kh + e] and W[n0+i][k + 4*kh + e], e = 0..3, from
-// one float4 each (the MFMA's two k-slots are k+e and k+4+e, the same permutation on both operands).
-// Both operands are K-contiguous, so fragments come straight from global/L2 with 16-byte loads:
-// with M <= a few hundred rows no two waves of a workgroup share a fragment and LDS staging would
-// only add a round trip (guide §5, "GEMV / M <= 16" row generalised to the split-K small-M case).
-// ------------------------------------------------------------------------------------------------
-template <int WK>
-__global__ __launch_bounds__(64 * WK) void gemm32(GemmBatch gb) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [WK][1024] partials (+ stats)
-    const GemmP& p = gb.g[blockIdx.z];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    if (m0 >= p.M || n0 >= p.N) return;
-    const int i = lane & 31, kh = lane >> 5;
-
-    int am = m0 + i;
-    if (am >= p.M) am = p.M - 1;
-    int wn = n0 + i;
-    if (wn >= p.N) wn = p.N - 1;
-    const float* arow = p.A + (long long)(am / p.a_n1) * p.a_s0 + (long long)((am % p.a_n1) / p.a_n2) * p.a_s1 +
-                        (long long)(am % p.a_n2) * p.a_s2;
-    const float* wrow = p.W + (long long)wn * p.ldw;
-
-    float mean = 0.f, rstd = 1.f;
-    const bool ln = p.ln_g != nullptr;
-    if (ln) {
-        // LayerNorm statistics of the tile's 32 rows over K = 256 (two-pass, float32).
-        float* st = smem + WK * 1024;
-        for (int r = wave; r < 32; r += WK) {
-            int rm = m0 + r;
-            if (rm >= p.M) rm = p.M - 1;
-            const float* rp = p.A + (long long)(rm / p.a_n1) * p.a_s0 + (long long)((rm % p.a_n1) / p.a_n2) * p.a_s1 +
-                              (long long)(rm % p.a_n2) * p.a_s2;
-            float4 v = *reinterpret_cast<const float4*>(rp + lane * 4);
-            float s = wave_sum(v.x + v.y + v.z + v.w);
-            float mu = s * (1.0f / 256.0f);
-            float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-            float q = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw);
-            if (lane == 0) {
-                st[r * 2] = mu;
-                st[r * 2 + 1] = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
-            }
-        }
-        __syncthreads();
-        mean = st[i * 2];
-        rstd = st[i * 2 + 1];
-    }
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    const int ks = p.K / WK;
-    const int k0 = wave * ks;
-    const int kend = k0 + ks;
-    int k = k0;
-    for (; k + 32 <= kend; k += 32) {
-        float4 a[4], w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = k + 8 * u + 4 * kh;
-            a[u] = *reinterpret_cast<const float4*>(arow + (long long)(kk / p.a_seg) * p.a_seg_stride + (kk % p.a_seg));
-            w[u] = *reinterpret_cast<const float4*>(wrow + kk);
-        }
-        if (ln) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kk = k + 8 * u + 4 * kh;
-                const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
-                const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
-                a[u].x = (a[u].x - mean) * rstd * g.x + b.x;
-                a[u].y = (a[u].y - mean) * rstd * g.y + b.y;
-                a[u].z = (a[u].z - mean) * rstd * g.z + b.z;
-                a[u].w = (a[u].w - mean) * rstd * g.w + b.w;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, w[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, w[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, w[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, w[u].w, acc, 0, 0, 0);
-        }
-    }
-    for (; k + 8 <= kend; k += 8) {
-        const int kk = k + 4 * kh;
-        float4 a = *reinterpret_cast<const float4*>(arow + (long long)(kk / p.a_seg) * p.a_seg_stride + (kk % p.a_seg));
-        const float4 w = *reinterpret_cast<const float4*>(wrow + kk);
-        if (ln) {
-            const float4 g = *reinterpret_cast<const float4*>(p.ln_g + kk);
-            const float4 b = *reinterpret_cast<const float4*>(p.ln_b + kk);
-            a.x = (a.x - mean) * rstd * g.x + b.x;
-            a.y = (a.y - mean) * rstd * g.y + b.y;
-            a.z = (a.z - mean) * rstd * g.z + b.z;
-            a.w = (a.w - mean) * rstd * g.w + b.w;
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
-    }
-
-    // split-K reduction through LDS in fixed wave order (deterministic, no atomics).
-#pragma unroll
-    for (int r = 0; r < 16; ++r) smem[wave * 1024 + r * 64 + lane] = acc[r];
-    __syncthreads();
-    constexpr int NT = 64 * WK;
-    constexpr int PER = 1024 / NT;   // WK <= 16 -> PER >= 1
-    float sums[PER > 0 ? PER : 1];
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int idx = tid + e * NT;
-        float s = smem[idx];
-#pragma unroll
-        for (int w2 = 1; w2 < WK; ++w2) s += smem[w2 * 1024 + idx];
-        sums[e] = s;
-    }
-    const int epi = p.epi;
-    if (epi == EPI_GLU || epi == EPI_LSTM) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            const int idx = tid + e * NT;
-            const int col = idx & 31;
-            smem[idx] = sums[e] + (p.bias ? p.bias[min(n0 + col, p.N - 1)] : 0.f);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int idx = tid + e * NT;
-        const int reg = idx >> 6, ln_ = idx & 63;
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (ln_ >> 5);
-        const int col = ln_ & 31;
-        const int m = m0 + row, n = n0 + col;
-        if (m >= p.M || n >= p.N) continue;
-        const long long crow = (long long)(m / p.c_n) * p.c_s0 + (long long)(((m % p.c_n) + p.c_r0) % p.c_mod) * p.c_s1;
-        if (epi == EPI_GLU) {
-            if (col & 1) continue;
-            const float a = smem[idx], g = smem[idx + 1];
-            p.C[crow + (n >> 1)] = a * sigmoidf_(g);
-        } else if (epi == EPI_LSTM) {
-            if (col & 3) continue;
-            const int tok = p.I[m];
-            const float4 t = *reinterpret_cast<const float4*>(p.X + (long long)tok * (4 * RNNT_D) + n);
-            const float gi = smem[idx] + t.x, gf = smem[idx + 1] + t.y, gg = smem[idx + 2] + t.z, go = smem[idx + 3] + t.w;
-            const int j = n >> 2;
-            const float cin = p.X2[(long long)m * RNNT_D + j];
-            const float c2 = sigmoidf_(gf) * cin + sigmoidf_(gi) * tanhf(gg);
-            const float h2 = sigmoidf_(go) * tanhf(c2);
-            p.C[(long long)m * RNNT_D + j] = h2;
-            p.Y2[(long long)m * RNNT_D + j] = c2;
-        } else {
-            float v = sums[e] + (p.bias ? p.bias[n] : 0.f);
-            if (epi == EPI_SILU) v = v * sigmoidf_(v);
-            else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
-            else if (epi == EPI_SCALE) v = v * p.alpha;
-            else if (epi == EPI_RESID) v = p.R[crow + n] + p.alpha * v;
-            else if (epi == EPI_DB) v = 10.0f * log10f(fmaxf(v, 1e-10f));
-            else if (epi == EPI_TANH_ADD) {
-                const int bi = m / p.x_n;
-                const int fr = p.I ? p.I[bi] : (m % p.x_n);
-                v = tanhf(v + p.X[(long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n]);
-            }
-            p.C[crow + n] = v;
-        }
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // gemm16<WK,NT>: the small-M workhorse.  One 16 x (16*NT) output tile per workgroup, K split over WK
@@ -293,15 +119,6 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
     int k = k0;
     for (; k + 16 * UN <= kend; k += 16 * UN) {
         float4 a[UN][MT], w[UN][NT];
-        if (p.dbg & 1) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[u][mt] = make_float4(1.f * k, 2.f, 3.f, 4.f + lane);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) w[u][t] = make_float4(1.f, 2.f * k, 3.f + lane, 4.f);
-            }
-        } else {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int kk = k + 16 * u + 4 * kq;
@@ -310,7 +127,6 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
             for (int mt = 0; mt < MT; ++mt) a[u][mt] = ldg4(arow[mt] + ko);
 #pragma unroll
             for (int t = 0; t < NT; ++t) w[u][t] = ldg4(wrow[t] + kk);
-        }
         }
         if (ln) {
 #pragma unroll
@@ -327,14 +143,6 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
                 }
             }
         }
-        if (p.dbg & 2) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[mt][t][0] += a[u][mt].x * w[u][t].x + a[u][mt].y * w[u][t].y + a[u][mt].z * w[u][t].z + a[u][mt].w * w[u][t].w;
-        } else
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
 #pragma unroll
@@ -385,15 +193,6 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
             }
     }
 
-    if (p.dbg & 4) {   // ablation: keep the accumulators alive, skip reduction and epilogue
-        float sacc = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) sacc += acc[mt][t][0] + acc[mt][t][1] + acc[mt][t][2] + acc[mt][t][3];
-        if (sacc == 12345.678f) p.C[0] = sacc;
-        return;
-    }
     // deterministic split-K reduction through LDS (fixed wave order)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -491,6 +290,46 @@ template <int WK, int MT, int NT>
 __global__ __launch_bounds__(64 * WK) void gemm16_tab(const GemmP* __restrict__ tab) {
     const GemmP p = tab[blockIdx.z];
     gemm16_body<WK, MT, NT>(p);
+}
+
+// Epilogue straight from the accumulators of an (16*MT) x (16*NT) wave sub-tile at (m0, n0): lane (i, kq) holds rows
+// 4*kq + r, column i of every 16x16 tile (the C/D layout is the same for the f32 and the 16-bit MFMA shapes).
+template <int MT, int NT>
+__device__ __forceinline__ void ns_epilogue(const GemmP& p, const f32x4_ (&acc)[MT][NT], int m0, int n0, int i, int kq) {
+    const int epi = p.epi;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + i;
+        const bool nin = n < p.N;
+        const float bias = (p.bias && nin) ? ldg1(p.bias + n) : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * mt + 4 * kq + r;
+                const bool inb = nin && m < p.M;
+                float v = acc[mt][t][r] + bias;
+                if (epi == EPI_GLU) {
+                    const float g = __shfl_xor(v, 1, 64);               // (value, gate) in adjacent columns / lanes
+                    if (inb && !(i & 1)) stg1(p.C + c_row_off(p, m) + (n >> 1), v * sigmoidf_(g));
+                    continue;
+                }
+                if (!inb) continue;
+                const long long crow = c_row_off(p, m);
+                if (epi == EPI_SILU) v = v * sigmoidf_(v);
+                else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+                else if (epi == EPI_SCALE) v = v * p.alpha;
+                else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
+                else if (epi == EPI_DB) v = 10.0f * log10f(fmaxf(v, 1e-10f));
+                else if (epi == EPI_TANH_ADD) {
+                    const int bi = fastdiv(m, p.x_n, p.x_n_magic, p.x_n_shift);
+                    const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
+                    v = tanhf(v + ldg1(p.X + (long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n));
+                }
+                stg1(p.C + crow + n, v);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,41 +524,7 @@ __device__ __forceinline__ void gemm_ns_body(const GemmP& p, int bx, int by) {
     const int m0 = bm0 + wm, n0 = bn0 + wn;
     if (m0 >= p.M || n0 >= p.N) return;     // this wave's sub-tile is out of range (all barriers are behind us)
 
-    // epilogue straight from the accumulators: lane (i, kq) holds rows 4*kq + r, column i of every 16x16 tile
-    const int epi = p.epi;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n0 + 16 * t + i;
-        const bool nin = n < p.N;
-        const float bias = (p.bias && nin) ? ldg1(p.bias + n) : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * mt + 4 * kq + r;
-                const bool inb = nin && m < p.M;
-                float v = acc[mt][t][r] + bias;
-                if (epi == EPI_GLU) {
-                    const float g = __shfl_xor(v, 1, 64);               // (value, gate) in adjacent columns / lanes
-                    if (inb && !(i & 1)) stg1(p.C + c_row_off(p, m) + (n >> 1), v * sigmoidf_(g));
-                    continue;
-                }
-                if (!inb) continue;
-                const long long crow = c_row_off(p, m);
-                if (epi == EPI_SILU) v = v * sigmoidf_(v);
-                else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
-                else if (epi == EPI_SCALE) v = v * p.alpha;
-                else if (epi == EPI_RESID) v = ldg1(p.R + crow + n) + p.alpha * v;
-                else if (epi == EPI_DB) v = 10.0f * log10f(fmaxf(v, 1e-10f));
-                else if (epi == EPI_TANH_ADD) {
-                    const int bi = fastdiv(m, p.x_n, p.x_n_magic, p.x_n_shift);
-                    const int fr = p.I ? ldgi(p.I + bi) : (m - bi * p.x_n);
-                    v = tanhf(v + ldg1(p.X + (long long)bi * p.x_s0 + (long long)fr * p.x_s1 + n));
-                }
-                stg1(p.C + crow + n, v);
-            }
-        }
-    }
+    ns_epilogue<MT, NT>(p, acc, m0, n0, i, kq);
     NS_STAMP(4)
 }
 

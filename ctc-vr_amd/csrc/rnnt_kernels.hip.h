@@ -2,6 +2,7 @@
 #pragma once
 #include "rnnt_common.hip.h"
 #include "rnnt_gemm.hip.h"
+#include "rnnt_gemm_bf.hip.h"
 #include "rnnt_encoder.hip.h"
 #include "rnnt_decode.hip.h"
 #include "rnnt_frontend.hip.h"

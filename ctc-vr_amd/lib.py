@@ -56,6 +56,20 @@ SIGNATURES = {
 
 _LIB = None
 
+# numerics modes of rnnt_finalize_weights (include/rnnt_hip.h RNNT_NUMERICS_*)
+NUMERICS = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}
+
+
+def numerics_id(mode=None):
+    """None -> $RNNT_NUMERICS or "fp32" (the exact-f32 parity mode); accepts the names above or their integer ids."""
+    if mode is None:
+        mode = os.environ.get("RNNT_NUMERICS", "fp32")
+    if isinstance(mode, str):
+        if mode not in NUMERICS:
+            raise ValueError(f"unknown numerics mode {mode!r}: one of {sorted(NUMERICS)}")
+        return NUMERICS[mode]
+    return int(mode)
+
 
 class RnntError(RuntimeError):
     pass
@@ -125,8 +139,8 @@ class RnntEngine:
             raise RnntError(f"{what}: {self.lib.rnnt_last_error(self.ctx).decode()} (status {rc})")
 
     # ---- weights ----------------------------------------------------------------------------
-    def load_state_dict(self, sd, stream=None):
-        """sd: name -> float32 numpy array or torch tensor (the reference's 504-key layout)."""
+    def load_state_dict(self, sd, stream=None, numerics=None):
+        """sd: name -> float32 numpy array or torch tensor (the reference's 504-key layout); numerics: see numerics_id."""
         for name, v in sd.items():
             if hasattr(v, "detach"):
                 v = v.detach().cpu().numpy()
@@ -135,7 +149,8 @@ class RnntEngine:
             a = np.ascontiguousarray(v, dtype=np.float32)
             dims = (c_i64 * max(a.ndim, 1))(*a.shape)
             self._chk(self.lib.rnnt_load_tensor(self.ctx, name.encode(), _np_ptr(a), a.ndim, dims), f"rnnt_load_tensor({name})")
-        self._chk(self.lib.rnnt_finalize_weights(self.ctx, 0, stream), "rnnt_finalize_weights")
+        self.numerics = numerics_id(numerics)
+        self._chk(self.lib.rnnt_finalize_weights(self.ctx, self.numerics, stream), "rnnt_finalize_weights")
 
     # ---- streaming --------------------------------------------------------------------------
     def reset(self, n_streams, stream=None):

@@ -101,7 +101,7 @@ class OnlineRNNTModel:
                  ctc_dropout_rate: float = 0.1, rnnt_loss_clamp: float = -1.0, ignore_id: int = -1,
                  # engine sizing (not in the reference)
                  max_streams: int = 1, max_chunk_frames: int = 256, max_cache_frames: int = 1024,
-                 max_enc_frames: int = 1024, max_tokens: int = 8192, device: int = 0, max_beam: int = 8):
+                 max_enc_frames: int = 1024, max_tokens: int = 8192, device: int = 0, max_beam: int = 8, numerics=None):
         if input_dim != 80 or hidden_dim != 256 or predictor_layers != 1:
             raise ValueError("the HIP path implements the reference's configured architecture: input_dim=80, hidden_dim=256, predictor_layers=1")
         self.blank_id = blank_id
@@ -116,6 +116,7 @@ class OnlineRNNTModel:
         self._engine = RnntEngine(max_streams=max_streams, max_chunk_frames=max_chunk_frames, max_cache_frames=max_cache_frames,
                                   max_enc_frames=max_enc_frames, max_tokens=max_tokens, vocab_size=vocab_size, blank_id=blank_id,
                                   n_steps=10, device=device, max_beam=max_beam)
+        self.numerics = numerics          # None -> $RNNT_NUMERICS or "fp32" (lib.numerics_id)
         self._loaded = False
         self._chunks_done = None          # None = reset_streaming_cache not called yet (attributes are None, :138-143)
         self._tok_count = 0
@@ -130,7 +131,7 @@ class OnlineRNNTModel:
         return self
 
     def load_state_dict(self, state_dict, strict: bool = True):
-        self._engine.load_state_dict(state_dict)
+        self._engine.load_state_dict(state_dict, numerics=self.numerics)
         self._loaded = True
 
     # ---- streaming state (model/online_rnnt_model.py:138-164) ----------------------------------------
@@ -354,7 +355,8 @@ class StreamingBatch:
     is B=1): the chunk loop of online_rnnt_decode.py:81-117 / streaming_inference for a whole batch."""
 
     def __init__(self, state_dict, n_streams: int, vocab_size: int = 412, blank_id: int = 5, max_chunk_frames: int = 64,
-                 max_cache_frames: int = 512, max_enc_frames: int = 512, max_tokens: int = 4096, device: int = 0, max_beam: int = 0):
+                 max_cache_frames: int = 512, max_enc_frames: int = 512, max_tokens: int = 4096, device: int = 0, max_beam: int = 0,
+                 numerics=None):
         self.device = torch.device("cuda", device)
         self.n = n_streams
         self.blank_id = blank_id
@@ -363,7 +365,7 @@ class StreamingBatch:
                                  n_steps=10, device=device, max_beam=max_beam)
         self.beams = None
         self.python_beam = False      # True: host half of the beam search in Python (beam_advance_frame), for tests
-        self.engine.load_state_dict(state_dict)
+        self.engine.load_state_dict(state_dict, numerics=numerics)
         self.offset = 0
 
     def reset(self):

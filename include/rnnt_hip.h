@@ -38,8 +38,16 @@ typedef enum {
     RNNT_ERR_STATE = -5     /* call sequence error (weights not finalized, no streams...) */
 } rnnt_status;
 
-/* numerics modes for rnnt_finalize_weights */
-#define RNNT_NUMERICS_FP32 0   /* fp32 storage, exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode */
+/* numerics modes for rnnt_finalize_weights: how the dense contractions of the encoder and of the joint lattice
+ * (positionwise_feed_forward.py:50-58, attention.py:109-131, subsampling.py:188-193, convolution.py:138-148,
+ * model/component/joint.py:62-69) are evaluated.  Storage is fp32 in every mode; LayerNorm, softmax, depthwise conv,
+ * the LSTM predictor and the greedy/beam decode arithmetic are fp32 in every mode. */
+#define RNNT_NUMERICS_FP32   0 /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain): default parity mode     */
+#define RNNT_NUMERICS_BF16X3 1 /* split bf16: x = hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32        */
+                               /* accumulate; ~1e-5 relative per product; parity-gated (tokens exact, logits <= 1e-3)      */
+#define RNNT_NUMERICS_BF16   2 /* plain bf16 operands, fp32 accumulate: perf mode, token-match rate reported, no parity   */
+#define RNNT_NUMERICS_F16X3  3 /* split f16 (11-bit planes): ~5e-7 relative per product, same cost as bf16x3; operands     */
+                               /* must stay below 65504 in magnitude (LayerNorm / activation outputs and weights do)       */
 
 typedef struct {
     int32_t max_streams;       /* B: lock-stepped streams held by the context                     */

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"librnnt_hip.so does not export {s}"
     assert sorted(rlib.SIGNATURES) == syms, "ctypes SIGNATURES and include/rnnt_hip.h disagree"
-    assert lib.rnnt_abi_version() == 2
+    assert lib.rnnt_abi_version() == 3
 
 
 def test_config_struct_layout():

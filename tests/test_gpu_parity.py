@@ -13,6 +13,15 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-3
+# parity-gated numerics modes (include/rnnt_hip.h RNNT_NUMERICS_*): every golden test below runs in each of them with the
+# same bars -- greedy tokens bit-exact, encoder outputs / logits within 1e-3.  Plain bf16 is a perf mode: test_bf16_perf_mode.
+PARITY_MODES = ["fp32", "bf16x3", "f16x3"]
+
+
+@pytest.fixture(params=PARITY_MODES)
+def numerics(request, monkeypatch):
+    monkeypatch.setenv("RNNT_NUMERICS", request.param)   # contexts created in the test pick it up (lib.numerics_id)
+    return request.param
 
 
 def maxdiff(a, b):
@@ -41,10 +50,15 @@ def models(np_state_dict):
     cache = {}
 
     def get(seed, chunk):
+        import os
+        key = (seed, os.environ.get("RNNT_NUMERICS", "fp32"))
+        return get2(key, seed, chunk)
+
+    def get2(seed, real_seed, chunk):
         if seed not in cache:
             m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=T.VOCAB, blank_id=T.BLANK, streaming=True,
                                 static_chunk_size=chunk, predictor_dropout=0)
-            m.load_state_dict(np_state_dict(seed))
+            m.load_state_dict(np_state_dict(real_seed))
             cache[seed] = m
         cache[seed].encoder.static_chunk_size = chunk
         return cache[seed]
@@ -52,7 +66,7 @@ def models(np_state_dict):
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_predictor_and_joint_step_api(seed, models):
+def test_predictor_and_joint_step_api(seed, models, numerics):
     m = models(seed, 16)
     eng = m._engine
     g = load_golden(f"modules_seed{seed}.npz")
@@ -80,7 +94,7 @@ def test_predictor_and_joint_step_api(seed, models):
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_forward_chunk_traces(seed, models):
+def test_forward_chunk_traces(seed, models, numerics):
     """Three consecutive 16-frame chunks: encoder output and both caches in the reference's layouts,
     including the dropped first-chunk K/V and the offset drift (§0.5)."""
     m = models(seed, 16)
@@ -109,7 +123,7 @@ STREAMS = ["syn0_c16_s0", "syn1_c16_s0", "syn0_c16_s1", "ex0_c32_s0", "ex0_c32_s
 
 
 @pytest.mark.parametrize("name", STREAMS)
-def test_decode_script_greedy_matches_reference(name, models):
+def test_decode_script_greedy_matches_reference(name, models, numerics):
     """online_rnnt_decode.py greedy loop through the facade's process_single_chunk: tokens bit-exact per
     chunk, final caches / predictor state / offsets as the reference left them."""
     g = load_golden(f"stream_{name}.npz")
@@ -136,7 +150,7 @@ def test_decode_script_greedy_matches_reference(name, models):
 
 
 @pytest.mark.parametrize("name", ["si_ex0_scs16_s0", "si_syn0_scs16_s0", "si_ex6_scs32_ms200_s0"])
-def test_streaming_inference_matches_reference(name, models):
+def test_streaming_inference_matches_reference(name, models, numerics):
     g = load_golden(f"stream_{name}.npz")
     m = models(int(g["seed"]), int(g["static_chunk_size"]))
     x = stream_input(name[3:])
@@ -147,7 +161,7 @@ def test_streaming_inference_matches_reference(name, models):
 
 
 @pytest.mark.parametrize("name", ["beam_ex6_c16_s0", "beam_syn0_c16_s1_f320", "beam_ex0_c32_s0"])
-def test_beam_search_matches_reference(name, models):
+def test_beam_search_matches_reference(name, models, numerics):
     """process_single_chunk_beam_search through the facade: after every chunk the beam (token lists in order,
     Python-double scores) equals the reference's (online_rnnt_model.py:389-522)."""
     g = load_golden(f"{name}.npz")
@@ -202,7 +216,7 @@ def test_native_beam_paths(np_state_dict, monkeypatch):
         assert abs(launched[b][0].log_prob - native[b][0].log_prob) < 1e-3, b
 
 
-def test_enc_out_full_trace(models):
+def test_enc_out_full_trace(models, numerics):
     g = load_golden("stream_syn0_c16_s0.npz")
     from ctc_vr_amd.online_rnnt_model import StreamingBatch  # noqa: F401
     m = models(0, 16)
@@ -222,7 +236,7 @@ def test_enc_out_full_trace(models):
     assert eng.tokens(s)[0] == g["tokens"].tolist()
 
 
-def test_batched_streams_equal_single_stream_reference(np_state_dict):
+def test_batched_streams_equal_single_stream_reference(np_state_dict, numerics):
     """B=6 lock-stepped streams (two distinct inputs interleaved): every stream equals the B=1 reference."""
     from ctc_vr_amd.online_rnnt_model import StreamingBatch
     g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
@@ -235,7 +249,7 @@ def test_batched_streams_equal_single_stream_reference(np_state_dict):
             assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (per_chunk, i)
 
 
-def test_wavefront_encoder_matches_chunk_by_chunk(np_state_dict):
+def test_wavefront_encoder_matches_chunk_by_chunk(np_state_dict, numerics):
     """rnnt_encoder_chunks (wavefront over chunk x layer, batched subsampling, LDS-tiled grouped GEMMs) vs
     chunk-by-chunk rnnt_encoder_chunk (split-K GEMMs): same arithmetic with a different K summation order, so
     encoder frames / caches agree to float32 rounding (1e-4 observed ~1e-6) and the tokens equal the reference."""
@@ -265,7 +279,7 @@ def test_wavefront_encoder_matches_chunk_by_chunk(np_state_dict):
     assert maxdiff(enc_seq[0], g0["enc_out"]) < LOGIT_TOL
 
 
-def test_full_size_properties(np_state_dict):
+def test_full_size_properties(np_state_dict, numerics):
     """BASELINE configs[1] at full size (64 streams x 1000 frames, chunk 16), size-independent properties:
     whole-utterance call == per-chunk API, run-to-run determinism, independence of a stream from its batch
     position and neighbours, and two of the streams against the CPU oracle (the bench checks eight)."""
@@ -308,7 +322,7 @@ def test_alternative_decoder_paths(np_state_dict, env, monkeypatch):
             assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (env, mode, i)
 
 
-def test_long_utterance_pipelined_equals_per_chunk(np_state_dict):
+def test_long_utterance_pipelined_equals_per_chunk(np_state_dict, numerics):
     """30 s utterances (562 cached keys per layer at the end, 186 chunks: many wavefront stages, streaming attention over
     several 64-key rounds, tail-merged last chunk): whole-utterance call == per-chunk API, for two chunk sizes."""
     from ctc_vr_amd.online_rnnt_model import StreamingBatch
@@ -320,7 +334,7 @@ def test_long_utterance_pipelined_equals_per_chunk(np_state_dict):
         assert min(len(t) for t in a) > 0
 
 
-def test_fresh_inputs_against_oracle(np_state_dict):
+def test_fresh_inputs_against_oracle(np_state_dict, numerics):
     """Seeded inputs no fixture covers: HIP (B=4, chunk 24) vs the CPU oracle run stream by stream."""
     from oracle import rnnt_oracle as O
     from ctc_vr_amd.online_rnnt_model import StreamingBatch
@@ -336,7 +350,7 @@ def test_fresh_inputs_against_oracle(np_state_dict):
     assert maxdiff(att, st.att_cache.numpy()) < LOGIT_TOL
 
 
-def test_encoder_full_context(models):
+def test_encoder_full_context(models, numerics):
     m = models(0, 16)
     eng = m._engine
     g = load_golden("full_seed0.npz")
@@ -344,6 +358,7 @@ def test_encoder_full_context(models):
     from ctc_vr_amd.lib import RnntEngine
     e2 = RnntEngine(max_streams=2, max_chunk_frames=320, max_cache_frames=128, max_enc_frames=8, vocab_size=T.VOCAB, blank_id=T.BLANK)
     e2.load_state_dict(T.make_state_dict(0))
+    assert e2.numerics == {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}[numerics]
     xd = x.cuda().contiguous()
     out = torch.empty(2, 74, 256, device="cuda")
     tq = e2.encoder_full(xd.data_ptr(), g["lens"], 2, 300, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -468,3 +483,29 @@ def test_error_paths(models):
         e.reset(1)                                                                # weights not finalized
     with pytest.raises(RnntError):
         e.load_state_dict({"encoder.after_norm.weight": np.ones(256, np.float32)})  # missing tensors
+
+
+def test_bf16_perf_mode(np_state_dict):
+    """RNNT_NUMERICS_BF16 (plain bf16 operands, fp32 accumulate) is a perf mode, not a parity mode: with top-2 logit margins
+    down to 3e-3 on these seeded weights bf16 arithmetic flips greedy tokens.  The bars here are only that it
+    runs the same path, stays close (encoder output within 0.1 of fp32 on values of magnitude ~3) and is deterministic; the
+    bench reports its token-match rate and encoder error next to its throughput instead of claiming parity."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    x = torch.from_numpy(T.synth_fbank(4, 1000)).cuda().contiguous()
+    plan = T.chunk_plan(1000, 16)
+    offs = [4 * i for i in range(len(plan))]
+    s = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for mode in ("fp32", "bf16"):
+        sb = StreamingBatch(np_state_dict(0), 4, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256, numerics=mode)
+        sb.reset()
+        sb.engine.encoder_chunks(x.data_ptr(), 1000, [a for a, _ in plan], [b - a for a, b in plan], offs, offs, s)
+        enc = sb.engine.enc_frames(s).copy()
+        toks = sb.decode_script(x, 16, pipelined=True)
+        assert sb.decode_script(x, 16, pipelined=True) == toks
+        res[mode] = (enc, toks)
+    err = maxdiff(res["bf16"][0], res["fp32"][0])
+    assert 1e-4 < err < 0.1, err          # really reduced precision, and still the same function
+    n_tok = sum(len(t) for t in res["fp32"][1])
+    same = sum(sum(int(a == b) for a, b in zip(p, q)) for p, q in zip(res["bf16"][1], res["fp32"][1]))
+    assert same > 0.3 * n_tok             # position-wise agreement before the first flip shifts a stream
