@@ -48,6 +48,15 @@ struct rnnt_ctx {
     float* blob = nullptr;
     size_t blob_floats = 0;
     unsigned short *blob_hi = nullptr, *blob_lo = nullptr;   // 16-bit hi / lo planes of the blob (split-operand numerics modes)
+    // fused Conformer-block kernels (rnnt_fused.hip.h): fragment-major packed layer weights of the current numerics mode and
+    // the per-layer pointer table in device memory
+    uint4* fuse_w = nullptr;
+    size_t fuse_w_vecs = 0;
+    LayerDev* layers_dev = nullptr;
+    int use_fused = 1;                         // RNNT_FUSED=0: the unfused wavefront (11 launches per stage)
+    FuseItem* wf_ftab = nullptr;
+    size_t wf_fcap = 0;
+    int wf_fused_plan = 0;                     // the cached plan (wf_key) was built for the fused schedule
     LayerW lw[L];
     const float *conv1_wt, *conv1_b, *conv2_w, *conv2_b, *emb_w, *emb_b, *pe, *after_g, *after_b;
     const float *ln_conv_g_all, *ln_conv_b_all, *glu0;

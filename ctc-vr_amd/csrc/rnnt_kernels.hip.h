@@ -8,3 +8,4 @@
 #include "rnnt_frontend.hip.h"
 #include "rnnt_beam.hip.h"
 #include "rnnt_misc.hip.h"
+#include "rnnt_fused.hip.h"
