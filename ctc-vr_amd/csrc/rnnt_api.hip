@@ -80,6 +80,9 @@ struct rnnt_ctx {
     int fuse_after_norm = 1;   // RNNT_FUSE_AFTER_NORM=0: keep after_norm as its own launch in the pipelined greedy path
     int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
+    int use_multi = 1;         // RNNT_DEC_MULTI=0: one CU per stream (greedy_stream) instead of greedy_multi (4 CUs per stream)
+    int n_cus = 0;
+    unsigned long long *gm_x1 = nullptr, *gm_xa = nullptr;   // greedy_multi mailboxes
     unsigned long long* flow_buf = nullptr;   // greedy_flow exchange words: xh [2][64][256] | xz [2][64][256] | xa [2][4][16][16][4]
     const float *wjc = nullptr, *bjc = nullptr;   // folded joint.pred_ffn o predictor.projection
     const float *wctc = nullptr, *bctc = nullptr; // ctc_head.ctc_lo (optional)

@@ -696,3 +696,356 @@ __global__ void probe_overlap_wait(int* ctrl, long long ticks) {
     }
     ctrl[1] = seen;
 }
+
+// ------------------------------------------------------------------------------------------------
+// greedy_multi<KF>: the resident greedy decoder with FOUR workgroups (CUs) per stream and the weights STATIONARY on chip.
+// greedy_stream streams 1.7 MB of weight rows through one CU per symbol (~23 us at the per-CU L2 fetch rate, ~2x that next to
+// the encoder), and the utterance batch ends with its slowest stream's dependent chain.  Here part p of stream b keeps for
+// the whole call
+//   W_hh rows of hidden units [64 p, 64 p + 64)  (256 gate rows x 256)      in registers (128 per thread)
+//   W_c  columns              [64 p, 64 p + 64)  (256 rows x 64, the folded pred_ffn o projection)  in registers (32 per thread)
+//   W_out rows                [ceil(V/4) p, ...) (103 x 256 for V = 412)                             in LDS
+// and a symbol costs two exchanges among the four parts instead of a weight stream:
+//   X1  h' slice (64) + the part's partial sums of W_c h' over its 64 columns (256)  ->  every part has h' and
+//       pp = b_c + sum of the four partials (added in part order, so all four hold the same bits)
+//   XA  per frame of the pass: the part's (max logit, argmax) over its vocabulary rows  ->  every part takes the same decision
+// (a run of blank frames costs one XA only: as in greedy_stream the predictor is re-evaluated only after a symbol and up to KF
+// frames share a pass).  Every exchanged 32-bit value travels as one 8-byte word (payload | tag << 32) written with one
+// write-through store and polled with L1-bypassing loads: valid iff the tag matches the exchange's sequence number; buffers
+// alternate by that number's parity (a part can only be one exchange ahead of the slowest of its group).  Same state machine and
+// per-logit operand order as the reference loop (online_rnnt_model.py:193-220); h' and pp are summed in a different (fixed)
+// order than greedy_stream's, i.e. equal to float32 rounding.  Needs 4 * B workgroups resident at once (B <= 64 on 256 CUs);
+// every wait is wall-clock bounded and an abort word releases the whole grid.
+// ------------------------------------------------------------------------------------------------
+#define GM_PARTS 4
+#define GM_X1 320            // words per part: 64 h' + 256 pp partials
+#define GM_WLD 260           // LDS row stride of the W_out slice (floats)
+struct DecMP {
+    const float* whh; const float* egate; const float* wjc; const float* bjc; const float* wout; const float* bout; const float* encp;
+    float* h; float* c;
+    int* sel; int* tok; int* fidx; int* nsym; int* count; int* tokens; int* ctrl;
+    unsigned long long* x1;      // [2][B][4][GM_X1]
+    unsigned long long* xa;      // [2][B][4][2 * KF]
+    long long fstride_f, bstride;
+    int B, vocab, blank, n_steps, max_tokens, n_total;
+    long long timeout_ticks;
+    const int* nlim;
+    int rows_per;                // ceil(vocab / 4): vocabulary rows of a part
+    int rows_lds;                // ... of which this many are resident in LDS (the rest is streamed from L2 every pass)
+};
+
+// spin until the word carries `tag`; false on abort / timeout (sets the error and abort words)
+__device__ __forceinline__ bool gm_poll(const DecMP& p, const unsigned long long* src, unsigned tag, unsigned& out) {
+    unsigned long long v = ld_tag(src);
+    if ((unsigned)(v >> 32) == tag) { out = (unsigned)v; return true; }
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    int it = 0;
+    while (true) {
+        v = ld_tag(src);
+        if ((unsigned)(v >> 32) == tag) { out = (unsigned)v; return true; }
+        if ((++it & 63) == 0) {
+            if (ld_sc1i(p.ctrl + 4) != 0) return false;
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                st_sc1i(p.ctrl + 1, 2);
+                st_sc1i(p.ctrl + 4, 1);
+                return false;
+            }
+        }
+    }
+}
+
+// 512 threads.  Where the 423 KB of a part's weights live: W_c in LDS (64 KB), W_out rows in LDS as far as the remaining LDS
+// reaches (88 of the 103 rows for V = 412; the last rows are streamed from L2 per pass, 15 KB), and the W_hh slice (256 KB) is
+// streamed from L2 once per SYMBOL with greedy_stream's 16-lanes-per-row loads.  (Keeping W_hh in registers was tried: as
+// plain arrays or parked in AGPRs through inline asm, hipcc spills the 128 weights of a thread to scratch at load time, which is
+// the same L2 stream with worse coalescing.)  So a symbol costs a quarter of greedy_stream's weight stream plus two exchanges,
+// and a run of blank frames one exchange and 15 KB.
+#define GM_CLD 68            // LDS row stride of the W_c slice (floats)
+template <int KF>
+__global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
+    extern __shared__ __attribute__((aligned(16))) float gm_smem[];
+    float* Wc = gm_smem;                                  // [256][GM_CLD]  W_c[:, 64 pw .. +64)
+    float* Wo = Wc + RNNT_D * GM_CLD;                     // [rows_lds][GM_WLD]
+    float* hs = Wo + p.rows_lds * GM_WLD;                 // [256] committed h
+    float* h2 = hs + RNNT_D;                              // [256] candidate h'
+    float* pp = h2 + RNNT_D;                              // [256] W_c h' + b_c
+    float* mypp = pp + RNNT_D;                            // [256] this part's partial
+    float* zs = mypp + RNNT_D;                            // [KF][256]
+    float* redv = zs + KF * RNNT_D;                       // [8 waves][KF]
+    int* redi = reinterpret_cast<int*>(redv + 8 * KF);    // [8][KF]
+    unsigned* xav = reinterpret_cast<unsigned*>(redi + 8 * KF);   // [4 parts][2 KF] gathered partials
+    int* s_bad = reinterpret_cast<int*>(xav + GM_PARTS * 2 * KF);
+    const int tid0 = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot >> 2) * 8 + xcd, pw = slot & 3;   // the four parts of a stream share blockIdx % 8 (one XCD: speed hint only)
+    if (b >= p.B) return;
+    // ---- resident weights ------------------------------------------------------------------------------------------------
+    const int cell_unit = 64 * pw + (tid0 >> 3);          // threads 0, 8, ... own the 64 hidden units of this part
+    const bool cell = (tid0 & 7) == 0;
+    const int v0 = p.rows_per * pw;                        // first vocabulary row of this part
+    float cc = 0.f, cc2 = 0.f;
+    float* gates = zs;                                     // [256] gate pre-activations of this part (zs is free during the predictor step)
+    {
+    const int tid = tid0;
+    for (int e = tid; e < RNNT_D * 16; e += 512) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        *reinterpret_cast<float4*>(&Wc[r * GM_CLD + c4]) = ldg4(p.wjc + (long long)r * RNNT_D + 64 * pw + c4);
+    }
+    for (int e = tid; e < p.rows_lds * 64; e += 512) {
+        const int r = e >> 6, c4 = (e & 63) * 4;
+        const int vr = v0 + r;
+        *reinterpret_cast<float4*>(&Wo[r * GM_WLD + c4]) = vr < p.vocab ? ldg4(p.wout + (long long)vr * RNNT_D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- state ---------------------------------------------------------------------------------------------------------------
+    const long long soff = (long long)(ldgi(p.sel + b) & 1) * p.bstride + (long long)b * RNNT_D;
+    if (tid < RNNT_D) hs[tid] = ldg1(p.h + soff + tid);
+    cc = cell ? ldg1(p.c + soff + cell_unit) : 0.f;
+    cc2 = cc;
+    if (tid == 0) *s_bad = 0;
+    }
+    int tok = ldgi(p.tok + b), fidx = ldgi(p.fidx + b), nsym = ldgi(p.nsym + b), count = ldgi(p.count + b);
+    const int n_total = p.nlim ? min(p.n_total, ldgi(p.nlim + b)) : p.n_total;
+    const float* encp = p.encp + (long long)b * p.fstride_f;
+    unsigned long long* x1b = p.x1 + (long long)b * GM_PARTS * GM_X1;
+    unsigned long long* xab = p.xa + (long long)b * GM_PARTS * 2 * KF;
+    const long long x1par = (long long)p.B * GM_PARTS * GM_X1, xapar = (long long)p.B * GM_PARTS * 2 * KF;
+    unsigned ev1 = 0, ev3 = 0;
+    int evals = 0, seen_ready = 0;
+    bool dirty = true, bad = false;
+    __syncthreads();
+    while (fidx < n_total) {
+        // Every index below is derived from an OPAQUE copy of the thread id made inside the iteration: with plain loop-invariant
+        // indices LLVM hoists a few hundred LDS / global address computations out of this loop and then spills them (and the
+        // resident weights) to scratch.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, row2 = tid >> 1, kh = tid & 1;
+        (void)lane;
+        // ---- frames available (bounded wait; the sequential schedule publishes everything before the launch) -----------------
+        int avail = seen_ready;
+        if (avail <= fidx) {
+            if (tid == 0) {
+                int nf = ld_sc1i(p.ctrl);
+                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                int err = 0;
+                while (nf <= fidx) {
+                    if (ld_sc1i(p.ctrl + 4) != 0 || (long long)__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+                        st_sc1i(p.ctrl + 1, 1);
+                        st_sc1i(p.ctrl + 4, 1);
+                        err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(16);
+                    nf = ld_sc1i(p.ctrl);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one acquire per publication seen
+                redi[0] = err ? -1 : nf;
+            }
+            __syncthreads();
+            avail = redi[0];
+            __syncthreads();
+            if (avail < 0) { bad = true; break; }
+            seen_ready = avail;
+        }
+        const int kf = dirty ? 1 : min(KF, min(avail, n_total) - fidx);
+        if (dirty) {
+            // ---- predictor step on this part's 64 units (predictor.py:200-204), then X1 ---------------------------------------
+            ++ev1;
+            unsigned long long* xw = x1b + (ev1 & 1) * x1par;
+            {
+                const float* eg = p.egate + (long long)tok * (4 * RNNT_D) + 256 * pw;
+                dec_matvec<1, 512, 2>(p.whh + (long long)(256 * pw) * RNNT_D, RNNT_D, reinterpret_cast<const float (*)[RNNT_D]>(hs),
+                                      [&](int n, const float* acc) { gates[n] = acc[0] + ldg1(eg + n); });
+            }
+            __syncthreads();
+            if (cell) {
+                const int unit = 64 * pw + (tid >> 3);
+                const float4 gt = *reinterpret_cast<const float4*>(&gates[4 * (tid >> 3)]);     // i, f, g, o of this unit
+                cc2 = sigmoidf_(gt.y) * cc + sigmoidf_(gt.x) * tanhf(gt.z);
+                const float hn = sigmoidf_(gt.w) * tanhf(cc2);
+                h2[unit] = hn;
+                st_tag(xw + pw * GM_X1 + (unit - 64 * pw), __float_as_uint(hn), ev1);
+            }
+            __syncthreads();
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 wv = *reinterpret_cast<const float4*>(&Wc[row2 * GM_CLD + 32 * kh + 4 * j]);
+                const float4 hv = *reinterpret_cast<const float4*>(&h2[64 * pw + 32 * kh + 4 * j]);
+                q0 = fmaf(wv.x, hv.x, q0);
+                q1 = fmaf(wv.y, hv.y, q1);
+                q0 = fmaf(wv.z, hv.z, q0);
+                q1 = fmaf(wv.w, hv.w, q1);
+            }
+            float part = q0 + q1;
+            part += __shfl_xor(part, 1, 64);
+            if (!kh) {
+                mypp[row2] = part;
+                st_tag(xw + pw * GM_X1 + 64 + row2, __float_as_uint(part), ev1);
+            }
+            __syncthreads();
+            // gather: threads 0..255 sum the four partials of pp[n] in part order; threads 256..447 fetch the other parts' h'
+            if (tid < RNNT_D) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < GM_PARTS; ++q) {
+                    float v = mypp[tid];
+                    if (q != pw) {
+                        unsigned w = 0;
+                        if (!gm_poll(p, xw + q * GM_X1 + 64 + tid, ev1, w)) bad = true;
+                        v = __uint_as_float(w);
+                    }
+                    sum = q == 0 ? v : sum + v;
+                }
+                pp[tid] = sum + ldg1(p.bjc + tid);
+            } else if (tid < RNNT_D + 192) {
+                const int idx = tid - RNNT_D;
+                int q = idx >> 6;
+                if (q >= pw) ++q;                              // the idx/64-th OTHER part
+                unsigned w = 0;
+                if (!gm_poll(p, xw + q * GM_X1 + (idx & 63), ev1, w)) bad = true;
+                h2[64 * q + (idx & 63)] = __uint_as_float(w);
+            }
+            if (bad) *s_bad = 1;
+            __syncthreads();
+            if (*s_bad) { bad = true; break; }
+            dirty = false;
+        }
+        // ---- joint activations of kf frames (every part computes all 256) ------------------------------------------------------
+        for (int e = tid; e < KF * RNNT_D; e += 512) {
+            const int k = e >> 8, n = e & 255;
+            zs[e] = k < kf ? tanhf(pp[n] + ldg1(encp + (long long)(fidx + k) * RNNT_D + n)) : 0.f;
+        }
+        __syncthreads();
+        // ---- logits of this part's vocabulary rows: thread = (row, quarter of K); argmax per frame --------------------------------
+        {
+            const int r = tid >> 2, qk = tid & 3;
+            const int vr = v0 + r;
+            const bool vin = r < p.rows_per && vr < p.vocab;
+            float acc[KF];
+#pragma unroll
+            for (int k = 0; k < KF; ++k) acc[k] = 0.f;
+            // two separate loops under ONE hoisted condition (a per-load "LDS or global" select makes hipcc branch around every
+            // load and spill hundreds of registers)
+            if (vin && r < p.rows_lds) {
+                const float* wl = &Wo[r * GM_WLD + 64 * qk];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float4 w = *reinterpret_cast<const float4*>(wl + 4 * j);
+#pragma unroll
+                    for (int k = 0; k < KF; ++k) {
+                        const float4 z = *reinterpret_cast<const float4*>(&zs[k * RNNT_D + 64 * qk + 4 * j]);
+                        acc[k] = fmaf(w.x, z.x, acc[k]);
+                        acc[k] = fmaf(w.y, z.y, acc[k]);
+                        acc[k] = fmaf(w.z, z.z, acc[k]);
+                        acc[k] = fmaf(w.w, z.w, acc[k]);
+                    }
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (vin) {
+                const float* wg = p.wout + (long long)vr * RNNT_D + 64 * qk;
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    float4 w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) w[u] = ldg4(wg + 16 * j4 + 4 * u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < KF; ++k) {
+                            const float4 z = *reinterpret_cast<const float4*>(&zs[k * RNNT_D + 64 * qk + 16 * j4 + 4 * u]);
+                            acc[k] = fmaf(w[u].x, z.x, acc[k]);
+                            acc[k] = fmaf(w[u].y, z.y, acc[k]);
+                            acc[k] = fmaf(w[u].z, z.z, acc[k]);
+                            acc[k] = fmaf(w[u].w, z.w, acc[k]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const float bo = vin ? ldg1(p.bout + vr) : 0.f;
+#pragma unroll
+            for (int k = 0; k < KF; ++k) {
+                float v = acc[k];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v = (vin && k < kf) ? v + bo : -INFINITY;
+                int ix = (vin && k < kf) ? vr : 0x7fffffff;
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) {             // over the 16 rows of this wave
+                    const float ov = __shfl_xor(v, o, 64);
+                    const int oi = __shfl_xor(ix, o, 64);
+                    if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+                }
+                if (lane == 0) { redv[wave * KF + k] = v; redi[wave * KF + k] = ix; }
+            }
+        }
+        __syncthreads();
+        ++ev3;
+        unsigned long long* xq = xab + (ev3 & 1) * xapar;
+        if (tid < KF) {
+            float v = redv[tid];
+            int ix = redi[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < 8; ++w2) {
+                const float ov = redv[w2 * KF + tid];
+                const int oi = redi[w2 * KF + tid];
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            unsigned u = 0u;
+            if (ix != 0x7fffffff) {
+                u = __float_as_uint(v);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // order-preserving; > 0 for every real value
+            }
+            st_tag(xq + pw * 2 * KF + 2 * tid, u, ev3);
+            st_tag(xq + pw * 2 * KF + 2 * tid + 1, (unsigned)ix, ev3);
+            xav[pw * 2 * KF + 2 * tid] = u;
+            xav[pw * 2 * KF + 2 * tid + 1] = (unsigned)ix;
+        } else if (tid >= 64 && tid < 64 + (GM_PARTS - 1) * 2 * KF) {
+            const int idx = tid - 64;
+            int q = idx / (2 * KF);
+            const int w = idx - q * 2 * KF;
+            if (q >= pw) ++q;
+            unsigned val = 0;
+            if (!gm_poll(p, xq + q * 2 * KF + w, ev3, val)) *s_bad = 1;
+            xav[q * 2 * KF + w] = val;
+        }
+        __syncthreads();
+        if (*s_bad) { bad = true; break; }
+        // ---- decisions, in frame order (identical in every thread of every part) ---------------------------------------------------
+        bool commit = false;
+        for (int k = 0; k < kf; ++k) {
+            unsigned bv = 0u;
+            int w = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < GM_PARTS; ++q) {
+                const unsigned v = xav[q * 2 * KF + 2 * k];
+                const int ix = (int)xav[q * 2 * KF + 2 * k + 1];
+                if (v > bv || (v == bv && ix < w)) { bv = v; w = ix; }
+            }
+            if (w == p.blank) { fidx += 1; nsym = 0; continue; }
+            if (pw == 0 && tid == 0 && count < p.max_tokens) p.tokens[(long long)b * p.max_tokens + count] = w;
+            count += 1;
+            tok = w;
+            nsym += 1;
+            if (nsym >= p.n_steps) { nsym = 0; fidx += 1; }
+            commit = true;
+            break;
+        }
+        __syncthreads();                                     // xav / redv fully consumed before the next pass rewrites them
+        if (commit) {
+            if (tid < RNNT_D) hs[tid] = h2[tid];
+            cc = cc2;
+            dirty = true;
+            __syncthreads();
+        }
+        ++evals;
+    }
+    // ---- canonical state for the host / the next call (buffer 0 becomes the committed one) ---------------------------------
+    if (pw == 0 && tid0 < RNNT_D) stg1(p.h + (long long)b * RNNT_D + tid0, hs[tid0]);
+    if (cell) stg1(p.c + (long long)b * RNNT_D + cell_unit, cc);
+    if (pw == 0 && tid0 == 0) {
+        p.sel[b] = 0; p.tok[b] = tok; p.fidx[b] = fidx; p.nsym[b] = nsym; p.count[b] = count;
+        atomicAdd(p.ctrl + 2, evals);
+    }
+    (void)bad;
+}
