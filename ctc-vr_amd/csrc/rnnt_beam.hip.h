@@ -18,49 +18,46 @@ struct BeamOut {
     int* n_active;    // [1]
 };
 
+// Any vocabulary size: strided passes over the row (the first version kept the row in 8 registers per lane and silently
+// ignored tokens >= 512); k <= 64 winners are excluded through a small LDS list.
 __global__ __launch_bounds__(64) void beam_reduce(const float* __restrict__ logits, int ldl, int vocab, int blank, int k, int step,
                                                 int n_steps, BeamOut o) {
+    __shared__ int chosen[64];
     const int r = blockIdx.x, lane = threadIdx.x;
     if (!o.active[r]) return;
     const float* x = logits + (long long)r * ldl;
-    float v[8];
     float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int idx = lane + 64 * j;
-        v[j] = idx < vocab ? x[idx] : -INFINITY;
-        mx = fmaxf(mx, v[j]);
-    }
+    for (int idx = lane; idx < vocab; idx += 64) mx = fmaxf(mx, x[idx]);
     mx = wave_max(mx);
     float se = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) se += (lane + 64 * j) < vocab ? expf(v[j] - mx) : 0.f;
+    for (int idx = lane; idx < vocab; idx += 64) se += expf(x[idx] - mx);
     const float lse = logf(wave_sum(se));
     const float blank_lp = (x[blank] - mx) - lse;
     const float max_lp = (mx - mx) - lse;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int idx = lane + 64 * j;
-        v[j] = (idx < vocab && idx != blank) ? (v[j] - mx) - lse : -INFINITY;
-    }
     int best_tok = 0;
     for (int t = 0; t < k; ++t) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (v[j] > bv) { bv = v[j]; bi = lane + 64 * j; }
+        for (int idx = lane; idx < vocab; idx += 64) {
+            if (idx == blank) continue;
+            bool taken = false;
+            for (int c = 0; c < t; ++c) taken = taken || chosen[c] == idx;
+            if (taken) continue;
+            const float lp = (x[idx] - mx) - lse;
+            if (lp > bv) { bv = lp; bi = idx; }          // ascending scan: ties keep the lower index
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float ov = __shfl_xor(bv, off, 64);
             const int oi = __shfl_xor(bi, off, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if ((bi & 63) == lane) v[bi >> 6] = -INFINITY;   // remove the winner
         if (lane == 0) {
+            chosen[t] = bi;
             o.top_lp[((long long)r * n_steps + step) * k + t] = bv;
             o.top_tok[((long long)r * n_steps + step) * k + t] = bi;
         }
+        __syncthreads();
         if (t == 0) best_tok = bi;
     }
     if (lane == 0) {

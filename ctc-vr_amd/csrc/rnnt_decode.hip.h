@@ -730,8 +730,8 @@ struct DecMP {
     int B, vocab, blank, n_steps, max_tokens, n_total;
     long long timeout_ticks;
     const int* nlim;
-    int rows_per;                // ceil(vocab / 4): vocabulary rows of a part
-    int rows_lds;                // ... of which this many are resident in LDS (the rest is streamed from L2 every pass)
+    int rows_per;                // ceil(vocab / 4): vocabulary rows of a part (<= 128), resident in LDS
+    long long* dbg;              // optional [16]: phase timers of workgroup (stream 0, part 0), 100 MHz ticks (RNNT_GM_DBG=1)
 };
 
 // spin until the word carries `tag`; false on abort / timeout (sets the error and abort words)
@@ -754,19 +754,20 @@ __device__ __forceinline__ bool gm_poll(const DecMP& p, const unsigned long long
     }
 }
 
-// 512 threads.  Where the 423 KB of a part's weights live: W_c in LDS (64 KB), W_out rows in LDS as far as the remaining LDS
-// reaches (88 of the 103 rows for V = 412; the last rows are streamed from L2 per pass, 15 KB), and the W_hh slice (256 KB) is
-// streamed from L2 once per SYMBOL with greedy_stream's 16-lanes-per-row loads.  (Keeping W_hh in registers was tried: as
+// 512 threads.  Where the 423 KB of a part's weights live: the W_out rows in LDS (107 KB for V = 412), the W_hh slice in
+// registers (128 per thread: row tid / 2, half of K) and the W_c columns in registers too (32 per thread): nothing is streamed
+// after the launch.  (GM_WHH_REGS=0 streams the W_hh slice from L2 per symbol instead, 4 us.)  (Keeping W_hh in registers was tried: as
 // plain arrays or parked in AGPRs through inline asm, hipcc spills the 128 weights of a thread to scratch at load time, which is
 // the same L2 stream with worse coalescing.)  So a symbol costs a quarter of greedy_stream's weight stream plus two exchanges,
 // and a run of blank frames one exchange and 15 KB.
-#define GM_CLD 68            // LDS row stride of the W_c slice (floats)
+#ifndef GM_WHH_REGS
+#define GM_WHH_REGS 1
+#endif
 template <int KF>
 __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
     extern __shared__ __attribute__((aligned(16))) float gm_smem[];
-    float* Wc = gm_smem;                                  // [256][GM_CLD]  W_c[:, 64 pw .. +64)
-    float* Wo = Wc + RNNT_D * GM_CLD;                     // [rows_lds][GM_WLD]
-    float* hs = Wo + p.rows_lds * GM_WLD;                 // [256] committed h
+    float* Wo = gm_smem;                                  // [rows_per][GM_WLD]  this part's vocabulary rows of W_out
+    float* hs = Wo + p.rows_per * GM_WLD;                 // [256] committed h
     float* h2 = hs + RNNT_D;                              // [256] candidate h'
     float* pp = h2 + RNNT_D;                              // [256] W_c h' + b_c
     float* mypp = pp + RNNT_D;                            // [256] this part's partial
@@ -775,6 +776,8 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
     int* redi = reinterpret_cast<int*>(redv + 8 * KF);    // [8][KF]
     unsigned* xav = reinterpret_cast<unsigned*>(redi + 8 * KF);   // [4 parts][2 KF] gathered partials
     int* s_bad = reinterpret_cast<int*>(xav + GM_PARTS * 2 * KF);
+    float* lpart = reinterpret_cast<float*>(s_bad + 4);      // [KF][4 quarters][128 rows] partial logits
+    static_assert(KF == 4, "thread (frame, row) mapping of the logit finish assumes KF * 128 == 512");
     const int tid0 = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot >> 2) * 8 + xcd, pw = slot & 3;   // the four parts of a stream share blockIdx % 8 (one XCD: speed hint only)
@@ -785,13 +788,27 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
     const int v0 = p.rows_per * pw;                        // first vocabulary row of this part
     float cc = 0.f, cc2 = 0.f;
     float* gates = zs;                                     // [256] gate pre-activations of this part (zs is free during the predictor step)
+#if GM_WHH_REGS
+    float whh_r[128];                                      // W_hh[256 pw + tid / 2][128 (tid & 1) .. +128)
+    {
+        const float* src = p.whh + (long long)(256 * pw + (tid0 >> 1)) * RNNT_D + 128 * (tid0 & 1);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float4 v = ldg4(src + 4 * j);
+            whh_r[4 * j] = v.x; whh_r[4 * j + 1] = v.y; whh_r[4 * j + 2] = v.z; whh_r[4 * j + 3] = v.w;
+        }
+    }
+#endif
+    // this part's columns of W_c: thread (row tid / 2, half of the 64 columns) holds 32 weights
+    float4 wcv[8];
+    {
+        const float* wc = p.wjc + (long long)(tid0 >> 1) * RNNT_D + 64 * pw + 32 * (tid0 & 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wcv[u] = ldg4(wc + 4 * u);
+    }
     {
     const int tid = tid0;
-    for (int e = tid; e < RNNT_D * 16; e += 512) {
-        const int r = e >> 4, c4 = (e & 15) * 4;
-        *reinterpret_cast<float4*>(&Wc[r * GM_CLD + c4]) = ldg4(p.wjc + (long long)r * RNNT_D + 64 * pw + c4);
-    }
-    for (int e = tid; e < p.rows_lds * 64; e += 512) {
+    for (int e = tid; e < p.rows_per * 64; e += 512) {
         const int r = e >> 6, c4 = (e & 63) * 4;
         const int vr = v0 + r;
         *reinterpret_cast<float4*>(&Wo[r * GM_WLD + c4]) = vr < p.vocab ? ldg4(p.wout + (long long)vr * RNNT_D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -812,6 +829,10 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
     unsigned ev1 = 0, ev3 = 0;
     int evals = 0, seen_ready = 0;
     bool dirty = true, bad = false;
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = (long long)__builtin_amdgcn_s_memrealtime();
+    const bool tdbg = p.dbg != nullptr && b == 0 && pw == 0 && tid0 == 0;
+#define GM_T(k) { if (tdbg) { const long long t_ = (long long)__builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tl; tl = t_; } }
+    int nsymev = 0;
     __syncthreads();
     while (fidx < n_total) {
         // Every index below is derived from an OPAQUE copy of the thread id made inside the iteration: with plain loop-invariant
@@ -848,16 +869,45 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
             seen_ready = avail;
         }
         const int kf = dirty ? 1 : min(KF, min(avail, n_total) - fidx);
+        // the encoder-projection rows of the pass are fetched now and used after the predictor step
+        float er[KF * RNNT_D / 512];
+#pragma unroll
+        for (int i2 = 0; i2 < KF * RNNT_D / 512; ++i2) {
+            const int e = tid + 512 * i2, k = e >> 8;
+            er[i2] = k < kf ? ldg1(encp + (long long)(fidx + k) * RNNT_D + (e & 255)) : 0.f;
+        }
+        GM_T(0)
         if (dirty) {
+            ++nsymev;
             // ---- predictor step on this part's 64 units (predictor.py:200-204), then X1 ---------------------------------------
             ++ev1;
             unsigned long long* xw = x1b + (ev1 & 1) * x1par;
+#if GM_WHH_REGS
+            {
+                const float eg = ldg1(p.egate + (long long)tok * (4 * RNNT_D) + 256 * pw + row2);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const float4 hv = *reinterpret_cast<const float4*>(&hs[128 * kh + 4 * j]);
+                    a0 = fmaf(whh_r[4 * j], hv.x, a0);
+                    a1 = fmaf(whh_r[4 * j + 1], hv.y, a1);
+                    a2 = fmaf(whh_r[4 * j + 2], hv.z, a2);
+                    a3 = fmaf(whh_r[4 * j + 3], hv.w, a3);
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                float g = (a0 + a1) + (a2 + a3);
+                g += __shfl_xor(g, 1, 64);
+                if (!kh) gates[row2] = g + eg;
+            }
+#else
             {
                 const float* eg = p.egate + (long long)tok * (4 * RNNT_D) + 256 * pw;
-                dec_matvec<1, 512, 2>(p.whh + (long long)(256 * pw) * RNNT_D, RNNT_D, reinterpret_cast<const float (*)[RNNT_D]>(hs),
+                dec_matvec<1, 512, 4>(p.whh + (long long)(256 * pw) * RNNT_D, RNNT_D, reinterpret_cast<const float (*)[RNNT_D]>(hs),
                                       [&](int n, const float* acc) { gates[n] = acc[0] + ldg1(eg + n); });
             }
+#endif
             __syncthreads();
+            GM_T(1)
             if (cell) {
                 const int unit = 64 * pw + (tid >> 3);
                 const float4 gt = *reinterpret_cast<const float4*>(&gates[4 * (tid >> 3)]);     // i, f, g, o of this unit
@@ -867,23 +917,25 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
                 st_tag(xw + pw * GM_X1 + (unit - 64 * pw), __float_as_uint(hn), ev1);
             }
             __syncthreads();
-            float q0 = 0.f, q1 = 0.f;
+            {
+                float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 wv = *reinterpret_cast<const float4*>(&Wc[row2 * GM_CLD + 32 * kh + 4 * j]);
-                const float4 hv = *reinterpret_cast<const float4*>(&h2[64 * pw + 32 * kh + 4 * j]);
-                q0 = fmaf(wv.x, hv.x, q0);
-                q1 = fmaf(wv.y, hv.y, q1);
-                q0 = fmaf(wv.z, hv.z, q0);
-                q1 = fmaf(wv.w, hv.w, q1);
-            }
-            float part = q0 + q1;
-            part += __shfl_xor(part, 1, 64);
-            if (!kh) {
-                mypp[row2] = part;
-                st_tag(xw + pw * GM_X1 + 64 + row2, __float_as_uint(part), ev1);
+                for (int u = 0; u < 8; ++u) {
+                    const float4 hv = *reinterpret_cast<const float4*>(&h2[64 * pw + 32 * kh + 4 * u]);   // two addresses per wave: broadcast
+                    q0 = fmaf(wcv[u].x, hv.x, q0);
+                    q1 = fmaf(wcv[u].y, hv.y, q1);
+                    q0 = fmaf(wcv[u].z, hv.z, q0);
+                    q1 = fmaf(wcv[u].w, hv.w, q1);
+                }
+                float part = q0 + q1;
+                part += __shfl_xor(part, 1, 64);
+                if (!kh) {
+                    mypp[row2] = part;
+                    st_tag(xw + pw * GM_X1 + 64 + row2, __float_as_uint(part), ev1);
+                }
             }
             __syncthreads();
+            GM_T(2)
             // gather: threads 0..255 sum the four partials of pp[n] in part order; threads 256..447 fetch the other parts' h'
             if (tid < RNNT_D) {
                 float sum = 0.f;
@@ -910,85 +962,71 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
             __syncthreads();
             if (*s_bad) { bad = true; break; }
             dirty = false;
+            GM_T(3)
         }
         // ---- joint activations of kf frames (every part computes all 256) ------------------------------------------------------
-        for (int e = tid; e < KF * RNNT_D; e += 512) {
-            const int k = e >> 8, n = e & 255;
-            zs[e] = k < kf ? tanhf(pp[n] + ldg1(encp + (long long)(fidx + k) * RNNT_D + n)) : 0.f;
+#pragma unroll
+        for (int i2 = 0; i2 < KF * RNNT_D / 512; ++i2) {
+            const int e = tid + 512 * i2, k = e >> 8;
+            zs[e] = k < kf ? tanhf(pp[e & 255] + er[i2]) : 0.f;
         }
         __syncthreads();
-        // ---- logits of this part's vocabulary rows: thread = (row, quarter of K); argmax per frame --------------------------------
+        // ---- logits of this part's vocabulary rows.  Thread (row = tid & 127, quarter of K = tid >> 7): a wave reads 64 consecutive
+        // rows at one quarter, so the 16 lanes of a ds_read_b128 cycle hit 16 distinct slots (row stride 260 floats) and z is a
+        // broadcast; the four quarter sums meet in LDS, then thread (frame, row) finishes the logit and the argmax runs per frame.
         {
-            const int r = tid >> 2, qk = tid & 3;
-            const int vr = v0 + r;
-            const bool vin = r < p.rows_per && vr < p.vocab;
-            float acc[KF];
-#pragma unroll
-            for (int k = 0; k < KF; ++k) acc[k] = 0.f;
-            // two separate loops under ONE hoisted condition (a per-load "LDS or global" select makes hipcc branch around every
-            // load and spill hundreds of registers)
-            if (vin && r < p.rows_lds) {
+            const int r = tid & 127, qk = tid >> 7;
+            if (r < p.rows_per) {
                 const float* wl = &Wo[r * GM_WLD + 64 * qk];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float4 w = *reinterpret_cast<const float4*>(wl + 4 * j);
+                for (int k = 0; k < KF; ++k) {
+                    if (k < kf) {   // one frame at a time: with the frames innermost hipcc SLP-packs across frames and spills ~90 registers
+                        const float* zk = &zs[k * RNNT_D + 64 * qk];
+                        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                    for (int k = 0; k < KF; ++k) {
-                        const float4 z = *reinterpret_cast<const float4*>(&zs[k * RNNT_D + 64 * qk + 4 * j]);
-                        acc[k] = fmaf(w.x, z.x, acc[k]);
-                        acc[k] = fmaf(w.y, z.y, acc[k]);
-                        acc[k] = fmaf(w.z, z.z, acc[k]);
-                        acc[k] = fmaf(w.w, z.w, acc[k]);
-                    }
-                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-            } else if (vin) {
-                const float* wg = p.wout + (long long)vr * RNNT_D + 64 * qk;
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) {
-                    float4 w[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) w[u] = ldg4(wg + 16 * j4 + 4 * u);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int k = 0; k < KF; ++k) {
-                            const float4 z = *reinterpret_cast<const float4*>(&zs[k * RNNT_D + 64 * qk + 16 * j4 + 4 * u]);
-                            acc[k] = fmaf(w[u].x, z.x, acc[k]);
-                            acc[k] = fmaf(w[u].y, z.y, acc[k]);
-                            acc[k] = fmaf(w[u].z, z.z, acc[k]);
-                            acc[k] = fmaf(w[u].w, z.w, acc[k]);
+                        for (int j = 0; j < 16; ++j) {
+                            const float4 w = *reinterpret_cast<const float4*>(wl + 4 * j);
+                            const float4 z = *reinterpret_cast<const float4*>(zk + 4 * j);
+                            a0 = fmaf(w.x, z.x, a0);
+                            a1 = fmaf(w.y, z.y, a1);
+                            a0 = fmaf(w.z, z.z, a0);
+                            a1 = fmaf(w.w, z.w, a1);
+                            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                         }
-                    __builtin_amdgcn_sched_barrier(0);
+                        lpart[(k * 4 + qk) * 128 + r] = a0 + a1;
+                    }
                 }
-            }
-            const float bo = vin ? ldg1(p.bout + vr) : 0.f;
-#pragma unroll
-            for (int k = 0; k < KF; ++k) {
-                float v = acc[k];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v = (vin && k < kf) ? v + bo : -INFINITY;
-                int ix = (vin && k < kf) ? vr : 0x7fffffff;
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) {             // over the 16 rows of this wave
-                    const float ov = __shfl_xor(v, o, 64);
-                    const int oi = __shfl_xor(ix, o, 64);
-                    if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-                }
-                if (lane == 0) { redv[wave * KF + k] = v; redi[wave * KF + k] = ix; }
             }
         }
         __syncthreads();
+        {
+            const int k = tid >> 7, r = tid & 127;         // KF * 128 = 512 threads
+            const int vr = v0 + r;
+            const bool vin = k < kf && r < p.rows_per && vr < p.vocab;
+            float v = -INFINITY;
+            int ix = 0x7fffffff;
+            if (vin) {
+                v = ((lpart[(k * 4) * 128 + r] + lpart[(k * 4 + 1) * 128 + r]) + (lpart[(k * 4 + 2) * 128 + r] + lpart[(k * 4 + 3) * 128 + r])) + ldg1(p.bout + vr);
+                ix = vr;
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(ix, o, 64);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            if (lane == 0) { redv[wave] = v; redi[wave] = ix; }   // wave 2 k, 2 k + 1 = frame k
+        }
+        __syncthreads();
+        GM_T(4)
         ++ev3;
         unsigned long long* xq = xab + (ev3 & 1) * xapar;
         if (tid < KF) {
-            float v = redv[tid];
-            int ix = redi[tid];
-#pragma unroll
-            for (int w2 = 1; w2 < 8; ++w2) {
-                const float ov = redv[w2 * KF + tid];
-                const int oi = redi[w2 * KF + tid];
+            float v = redv[2 * tid];
+            int ix = redi[2 * tid];
+            {
+                const float ov = redv[2 * tid + 1];
+                const int oi = redi[2 * tid + 1];
                 if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
             }
             unsigned u = 0u;
@@ -1010,6 +1048,7 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
             xav[q * 2 * KF + w] = val;
         }
         __syncthreads();
+        GM_T(5)
         if (*s_bad) { bad = true; break; }
         // ---- decisions, in frame order (identical in every thread of every part) ---------------------------------------------------
         bool commit = false;
@@ -1039,7 +1078,13 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
             __syncthreads();
         }
         ++evals;
+        GM_T(6)
     }
+    if (tdbg) {
+        for (int k = 0; k < 8; ++k) p.dbg[k] = tacc[k];
+        p.dbg[8] = evals; p.dbg[9] = nsymev;
+    }
+#undef GM_T
     // ---- canonical state for the host / the next call (buffer 0 becomes the committed one) ---------------------------------
     if (pw == 0 && tid0 < RNNT_D) stg1(p.h + (long long)b * RNNT_D + tid0, hs[tid0]);
     if (cell) stg1(p.c + (long long)b * RNNT_D + cell_unit, cc);

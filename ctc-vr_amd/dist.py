@@ -1,46 +1,77 @@
 """Multi-GPU plumbing: utterances (streams) shard across ranks with no data-path collective;
-the only collective is one broadcast of the packed weight blob from the source rank (RCCL over xGMI on the
-GPU box: torch.distributed backend "nccl"; gloo on CPU in the tests)."""
+the only collectives are a 2-word header and one broadcast of the packed weight blob from the source rank (RCCL over xGMI on
+the GPU box: torch.distributed backend "nccl"; gloo on CPU in the tests)."""
 import numpy as np
 import torch
 
 from . import testing as T
 
 
-def pack_state_dict(sd):
-    """Flat float32 vector in state_dict_spec() order (num_batches_tracked slots are zero)."""
-    spec = T.state_dict_spec()
-    return np.concatenate([np.asarray(sd[n], np.float32).reshape(-1) if k != "nbt" else np.zeros(1, np.float32)
-                           for (n, _, k) in spec])
+def vocab_of(sd):
+    """Vocabulary size of a state dict in the reference's 504-key layout (rows of joint.ffn_out.weight)."""
+    return int(np.asarray(sd["joint.ffn_out.weight"]).shape[0])
 
 
-def unpack_state_dict(flat):
+def pack_state_dict(sd, vocab=None):
+    """Flat float32 vector in state_dict_spec(vocab) order (num_batches_tracked slots are zero).  Raises on a missing key,
+    a key the layout does not know or a wrong shape: a silently different layout would corrupt the broadcast."""
+    vocab = vocab_of(sd) if vocab is None else vocab
+    spec = T.state_dict_spec(vocab)
+    names = {n for n, _, _ in spec}
+    extra = [k for k in sd if k not in names]
+    if extra:
+        raise KeyError(f"state dict has keys outside the 504-key layout: {extra[:4]}")
+    parts = []
+    for (n, shp, k) in spec:
+        if k == "nbt":
+            parts.append(np.zeros(1, np.float32))
+            continue
+        if n not in sd:
+            raise KeyError(f"state dict lacks {n}")
+        a = np.asarray(sd[n], np.float32)
+        if tuple(a.shape) != tuple(shp):
+            raise ValueError(f"{n}: shape {tuple(a.shape)}, layout says {tuple(shp)}")
+        parts.append(a.reshape(-1))
+    return np.concatenate(parts)
+
+
+def unpack_state_dict(flat, vocab=T.VOCAB):
     out, o = {}, 0
-    for (n, s, k) in T.state_dict_spec():
+    for (n, s, k) in T.state_dict_spec(vocab):
         sz = int(np.prod(s)) if s else 1
         if k != "nbt":
             out[n] = np.asarray(flat[o:o + sz], np.float32).reshape(s)
         o += sz
-    assert o == len(flat)
+    if o != len(flat):
+        raise ValueError(f"blob of {len(flat)} floats does not match the layout for vocab {vocab} ({o} floats)")
     return out
 
 
-def blob_size():
-    return sum(int(np.prod(s)) if s else 1 for _, s, _ in T.state_dict_spec())
+def blob_size(vocab=T.VOCAB):
+    return sum(int(np.prod(s)) if s else 1 for _, s, _ in T.state_dict_spec(vocab))
 
 
 def broadcast_state_dict(sd, src=0, device="cpu"):
-    """Rank `src` passes its state dict (others pass None); every rank returns the same dict.
-    One collective: dist.broadcast of ~88 MB float32."""
+    """Rank `src` passes its state dict (others pass None); every rank returns the same dict.  The layout is derived on the
+    source rank: a 2-word header (vocabulary size, blob length) goes first, then ONE dist.broadcast of the ~88 MB float32 blob."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sd
-    if dist.get_rank() == src:
-        blob = torch.from_numpy(pack_state_dict(sd)).to(device)
+    is_src = dist.get_rank() == src
+    hdr_dev = device if dist.get_backend() == "nccl" else "cpu"
+    if is_src:
+        vocab = vocab_of(sd)
+        flat = pack_state_dict(sd, vocab)
+        hdr = torch.tensor([vocab, flat.size], dtype=torch.int64, device=hdr_dev)
     else:
-        blob = torch.empty(blob_size(), dtype=torch.float32, device=device)
+        hdr = torch.zeros(2, dtype=torch.int64, device=hdr_dev)
+    dist.broadcast(hdr, src=src)
+    vocab, n = int(hdr[0]), int(hdr[1])
+    if n != blob_size(vocab):
+        raise ValueError(f"source rank announced {n} floats for vocab {vocab}; this rank's layout has {blob_size(vocab)}")
+    blob = torch.from_numpy(flat).to(device) if is_src else torch.empty(n, dtype=torch.float32, device=device)
     dist.broadcast(blob, src=src)
-    return unpack_state_dict(blob.cpu().numpy())
+    return unpack_state_dict(blob.cpu().numpy(), vocab)
 
 
 def shard_range(n_total, rank, world):

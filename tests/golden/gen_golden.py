@@ -307,6 +307,45 @@ def gen_offline():
         save(f"offline_greedy_seed{seed}.npz", lens=lens.numpy(), out_lens=out_lens.numpy(), **out)
 
 
+@torch.no_grad()
+def gen_ctc():
+    """CTC head: OnlineCTC.log_softmax / argmax (model/online_rnnt_model.py:34-38) and the reference's own ctc_greedy_search
+    (:647-671) on the DETERMINISTIC full-context encoder.  The method itself calls self.encoder(audios, audio_lens), which draws a
+    random dynamic-chunk mask even in eval; here the encoder's forward is given decoding_chunk_size=-1, everything
+    else (log_softmax, argmax, collapse loop) is the reference's code."""
+    for seed in (0, 1):
+        net = build(seed, 16)
+        x = torch.from_numpy(T.synth_fbank(2, 300, seed=99 + seed))
+        lens = torch.tensor([300, 203])
+        enc_fwd = net.encoder.forward
+        net.encoder.forward = lambda xs, xl, *a, **k: enc_fwd(xs, xl, decoding_chunk_size=-1)
+        hyps = net.ctc_greedy_search(x, lens)
+        y, m = net.encoder(x, lens)
+        lp = net.ctc_head.log_softmax(y)
+        ids = net.ctc_head.argmax(y)
+        top2 = lp.topk(2, dim=2).values
+        flat, cnt = pack_tokens(hyps)
+        save(f"ctc_seed{seed}.npz", lens=lens.numpy(), fbank_seed=np.int64(99 + seed), ids=ids.numpy().astype(np.int64), mask=m.numpy(),
+             hyp_tokens=flat, hyp_counts=cnt, logp_first8=f32(lp[:, :8]), logp_rowmax=f32(lp.max(dim=2).values),
+             min_margin=np.float32((top2[..., 0] - top2[..., 1]).min().item()))
+
+
+@torch.no_grad()
+def gen_prefix():
+    """WeNet prefix beam search (wenet/transducer/search/prefix_beam_search.py:42-148) run as the reference class on the model's
+    own encoder / predictor / joint / CTC head, full context (decoding_chunk_size=-1), B = 1."""
+    from wenet.transducer.search.prefix_beam_search import PrefixBeamSearch
+    for seed, frames, beam in ((0, 240, 4), (1, 171, 5)):
+        net = build(seed, 16)
+        x = torch.from_numpy(T.synth_fbank(1, frames, seed=55 + seed))
+        pbs = PrefixBeamSearch(net.encoder, net.predictor, net.joint, net.ctc_head, net.blank_id)
+        beam_out, enc = pbs.prefix_beam_search(x, torch.tensor([frames]), decoding_chunk_size=-1, beam_size=beam, ctc_weight=0.3, transducer_weight=0.7)
+        flat, cnt = pack_tokens([[int(t) for t in s.hyp] for s in beam_out])
+        save(f"prefix_beam_seed{seed}.npz", frames=np.int64(frames), fbank_seed=np.int64(55 + seed), beam=np.int64(beam), hyp_tokens=flat, hyp_counts=cnt,
+             scores=np.array([float(s.score) for s in beam_out], np.float64), enc_frames=np.int64(enc.size(1)),
+             h=f32(torch.cat([s.cache[0] for s in beam_out], 1)), c=f32(torch.cat([s.cache[1] for s in beam_out], 1)))
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
     if len(sys.argv) > 1 and sys.argv[1] == "cer":
@@ -315,6 +354,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "offline":
         gen_offline()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("ctc", "prefix"):
+        (gen_ctc if sys.argv[1] == "ctc" else gen_prefix)()
+        sys.exit(0)
     inp = gen_inputs()
     gen_modules(0, inp)
     gen_modules(1, inp)
@@ -322,3 +364,5 @@ if __name__ == "__main__":
     gen_full(inp)
     gen_cer()
     gen_offline()
+    gen_ctc()
+    gen_prefix()

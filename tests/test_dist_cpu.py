@@ -26,6 +26,11 @@ def _worker(rank, world, port, q):
     got = D.broadcast_state_dict(sd, src=0, device="cpu")
     ref = T.make_state_dict(3)
     same = all(np.array_equal(got[k], ref[k]) for k in got) and len(got) == 504 - 12
+    # a vocabulary the receiving ranks do not know in advance: the layout travels in the header
+    sd2 = T.make_state_dict(4, vocab=77, blank=3) if rank == 0 else None
+    got2 = D.broadcast_state_dict(sd2, src=0, device="cpu")
+    ref2 = T.make_state_dict(4, vocab=77, blank=3)
+    same = same and got2["joint.ffn_out.weight"].shape == (77, 256) and all(np.array_equal(got2[k], ref2[k]) for k in got2)
     lo, hi = D.shard_range(130, rank, world)
     # every rank decodes only its own streams; a tiny all_gather of counts stands in for result collection
     mine = torch.tensor([hi - lo], dtype=torch.int64)
@@ -58,6 +63,17 @@ def test_pack_unpack_roundtrip_and_ranges():
     assert flat.dtype == np.float32 and flat.size == D.blob_size()
     back = D.unpack_state_dict(flat)
     assert all(np.array_equal(back[k], sd[k]) for k in back)
+    sd77 = T.make_state_dict(1, vocab=77, blank=3)
+    flat77 = D.pack_state_dict(sd77)
+    assert flat77.size == D.blob_size(77) != D.blob_size()
+    assert all(np.array_equal(v, sd77[k]) for k, v in D.unpack_state_dict(flat77, 77).items())
+    import pytest
+    with pytest.raises(ValueError):
+        D.unpack_state_dict(flat77)                      # wrong vocabulary for this blob
+    with pytest.raises(KeyError):
+        D.pack_state_dict({k: v for k, v in sd.items() if k != "joint.enc_ffn.bias"})
+    with pytest.raises(KeyError):
+        D.pack_state_dict(dict(sd, bogus=np.zeros(3, np.float32)))
     cover = []
     for r in range(8):
         lo, hi = D.shard_range(512, r, 8)

@@ -369,18 +369,28 @@ def test_encoder_full_context(models, numerics):
     del eng
 
 
-def test_ctc_greedy_search_against_oracle(models, np_state_dict):
-    """CTC head on the full-context encoder vs the oracle (argmax exact, collapse rule)."""
-    from oracle import rnnt_oracle as O
+@pytest.mark.parametrize("seed", [0, 1])
+def test_ctc_greedy_search_matches_reference(seed, np_state_dict, numerics):
+    """CTC head on the full-context encoder against the reference's own OnlineCTC.argmax and ctc_greedy_search
+    (model/online_rnnt_model.py:34-38,647-671; golden ctc_seed*.npz from gen_golden.py: per-frame argmax ids on the valid frames
+    and the collapsed hypotheses, every numerics mode; the fixture's smallest top-2 log-prob margin is recorded next to them)."""
     from ctc_vr_amd.online_rnnt_model import OnlineRNNTModel
+    g = load_golden(f"ctc_seed{seed}.npz")
     m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=T.VOCAB, blank_id=T.BLANK, max_streams=2, max_chunk_frames=320,
                         max_cache_frames=128, max_enc_frames=128, max_beam=0)
-    m.load_state_dict(np_state_dict(0))
-    x = torch.from_numpy(T.synth_fbank(2, 300, seed=99))
-    lens = torch.tensor([300, 203])
+    m.load_state_dict(np_state_dict(seed))
+    x = torch.from_numpy(T.synth_fbank(2, 300, seed=int(g["fbank_seed"])))
+    lens = torch.from_numpy(g["lens"])
     got = m.ctc_greedy_search(x, lens)
-    want = O.ctc_greedy_search_full(O.to_torch_sd(np_state_dict(0)), x, lens, T.BLANK)
+    want, o = [], 0
+    for c in g["hyp_counts"].tolist():
+        want.append(g["hyp_tokens"][o:o + c].tolist())
+        o += c
     assert got == want and len(got[0]) > 0
+    ids = m._engine.ctc_argmax(x.cuda().contiguous().data_ptr(), lens.numpy(), 2, 300, torch.cuda.current_stream().cuda_stream)
+    valid = g["mask"][:, 0, :]
+    assert np.array_equal(ids[valid], g["ids"][valid])
+    assert float(g["min_margin"]) > 1e-3
 
 
 def test_fbank_frontend_against_oracle(models):
@@ -509,3 +519,32 @@ def test_bf16_perf_mode(np_state_dict):
     n_tok = sum(len(t) for t in res["fp32"][1])
     same = sum(sum(int(a == b) for a, b in zip(p, q)) for p, q in zip(res["bf16"][1], res["fp32"][1]))
     assert same > 0.3 * n_tok             # position-wise agreement before the first flip shifts a stream
+
+
+def test_large_vocabulary_paths():
+    """Vocabulary > 512 (the reference's default constructor vocabulary is 4336): the beam search takes the launched extension
+    steps (beam_reduce scans the row in strides: its first version kept 512 entries in registers and silently ignored the rest),
+    greedy decode takes the one-CU-per-stream decoder (greedy_multi holds <= 128 vocabulary rows per part).  Checked against the
+    CPU oracle on a seeded 600-token model whose best tokens are spread over the whole range."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_model import OnlineRNNTModel
+    V, blank = 600, 5
+    sd_np = T.make_state_dict(5, vocab=V, blank=blank, blank_bias=11.0, out_gain=6.0)   # 56 tokens on this input, 10 of them >= 512
+    sd = O.to_torch_sd(sd_np)
+    x = torch.from_numpy(T.synth_fbank(1, 192, seed=31))
+    m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=V, blank_id=blank, streaming=True, static_chunk_size=16, predictor_dropout=0)
+    m.load_state_dict(sd_np)
+    want, _, _ = O.decode_script_greedy(sd, x, 16, blank=blank)
+    m.reset_streaming_cache()
+    got = []
+    for (a, b) in T.chunk_plan(192, 16):
+        got.extend(m.process_single_chunk(x[:, a:b], torch.tensor([b - a]))[0])
+    assert got == want and max(want) >= 512, (max(want), len(want))
+    st = O.OracleStream(sd, blank, 16)
+    m.reset_streaming_cache()
+    for (a, b) in T.chunk_plan(192, 16):
+        ob = st.process_single_chunk_beam_search(x[:, a:b], beam_size=4)
+        hb, _, _ = m.process_single_chunk_beam_search(x[:, a:b], torch.tensor([b - a]), beam_size=4)
+        assert [h.tokens for h in hb] == [h.tokens for h in ob]
+        assert max(abs(p.log_prob - q.log_prob) for p, q in zip(hb, ob)) < 2e-3
+    assert any(t >= 512 for h in hb for t in h.tokens)

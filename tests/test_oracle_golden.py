@@ -182,3 +182,24 @@ def test_offline_greedy_search(seed, np_state_dict):
         cnt = g[f"counts_n{n_steps}"]
         assert [len(h) for h in hyps] == cnt.tolist()
         assert [t for h in hyps for t in h] == g[f"tokens_n{n_steps}"].tolist()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_ctc_head_matches_reference(seed):
+    """oracle ctc_greedy_search_full vs the reference's ctc_greedy_search / OnlineCTC.argmax on the deterministic full-context
+    encoder (golden ctc_seed*.npz)."""
+    g = load_golden(f"ctc_seed{seed}.npz")
+    sd = O.to_torch_sd(T.make_state_dict(seed))
+    x = torch.from_numpy(T.synth_fbank(2, 300, seed=int(g["fbank_seed"])))
+    lens = torch.from_numpy(g["lens"])
+    got = O.ctc_greedy_search_full(sd, x, lens, T.BLANK)
+    want, o = [], 0
+    for c in g["hyp_counts"].tolist():
+        want.append(g["hyp_tokens"][o:o + c].tolist())
+        o += c
+    assert got == want
+    enc, mask = O.encoder_full(sd, x, lens)
+    lp = torch.log_softmax(torch.nn.functional.linear(enc, sd["ctc_head.ctc_lo.weight"], sd["ctc_head.ctc_lo.bias"]), dim=2)
+    valid = g["mask"][:, 0, :]
+    assert np.array_equal(lp.argmax(2).numpy()[valid], g["ids"][valid])
+    assert np.abs(lp[:, :8].numpy() - g["logp_first8"]).max() < 1e-4
