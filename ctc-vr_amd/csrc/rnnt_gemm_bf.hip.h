@@ -312,6 +312,12 @@ __global__ __launch_bounds__(256) void gemm_bf_tab(const GemmP* __restrict__ tab
 // planes): there is no [B,T,U,256] intermediate anywhere.  The two column halves of a row exchange (max, sum) through LDS.
 // Rows go out with non-temporal stores (written once, larger than the Infinity Cache).
 // ------------------------------------------------------------------------------------------------
+// tanh for the lattice's A operand: 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp (abs error ~2e-7 on |x| < 10, saturates cleanly);
+// the libm tanhf costs as many VALU cycles per workgroup as the whole MFMA work of the tile (32 K evaluations)
+__device__ __forceinline__ float jl_tanh(float x) {
+    const float e = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
 #define JL_BM 128
 #define JL_NT 13                 // column tiles per wave: 2 * 13 * 16 = 416 columns >= vocab
 struct JointLP {
@@ -370,8 +376,8 @@ __global__ __launch_bounds__(512) void joint_lattice(JointLP P) {
     };
     auto lstore = [&](int buf) {
         float4 v0, v1;
-        v0.x = tanhf(re[0].x + rp[0].x); v0.y = tanhf(re[0].y + rp[0].y); v0.z = tanhf(re[0].z + rp[0].z); v0.w = tanhf(re[0].w + rp[0].w);
-        v1.x = tanhf(re[1].x + rp[1].x); v1.y = tanhf(re[1].y + rp[1].y); v1.z = tanhf(re[1].z + rp[1].z); v1.w = tanhf(re[1].w + rp[1].w);
+        v0.x = jl_tanh(re[0].x + rp[0].x); v0.y = jl_tanh(re[0].y + rp[0].y); v0.z = jl_tanh(re[0].z + rp[0].z); v0.w = jl_tanh(re[0].w + rp[0].w);
+        v1.x = jl_tanh(re[1].x + rp[1].x); v1.y = jl_tanh(re[1].y + rp[1].y); v1.z = jl_tanh(re[1].z + rp[1].z); v1.w = jl_tanh(re[1].w + rp[1].w);
         uint4 h, l;
         split8_16<F16, LO>(v0, v1, h, l);
         const int slot = srow * 4 + (sc ^ bf_swz(srow));
@@ -435,6 +441,12 @@ __global__ __launch_bounds__(512) void joint_lattice(JointLP P) {
         nin[t] = n < P.V;
         bias[t] = nin[t] ? ldg1(P.bias + n) : 0.f;
     }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < JL_NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][t][r] += bias[t];
     float lse[2][4];
     if constexpr (LSM) {
 #pragma unroll
@@ -443,12 +455,12 @@ __global__ __launch_bounds__(512) void joint_lattice(JointLP P) {
             for (int r = 0; r < 4; ++r) {
                 float mx = -INFINITY;
 #pragma unroll
-                for (int t = 0; t < JL_NT; ++t) mx = fmaxf(mx, nin[t] ? acc[mt][t][r] + bias[t] : -INFINITY);
+                for (int t = 0; t < JL_NT; ++t) mx = fmaxf(mx, nin[t] ? acc[mt][t][r] : -INFINITY);
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
                 float sm = 0.f;
 #pragma unroll
-                for (int t = 0; t < JL_NT; ++t) sm += nin[t] ? expf(acc[mt][t][r] + bias[t] - mx) : 0.f;
+                for (int t = 0; t < JL_NT; ++t) sm += nin[t] ? __expf(acc[mt][t][r] - mx) : 0.f;
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
                 if (i == 0) {
@@ -465,22 +477,31 @@ __global__ __launch_bounds__(512) void joint_lattice(JointLP P) {
                 const int row = wm + 16 * mt + 4 * kq + r;
                 const float m0_ = rstat[row * 2], s0 = rstat[row * 2 + 1], m1 = rstat[(JL_BM + row) * 2], s1 = rstat[(JL_BM + row) * 2 + 1];
                 const float mx = fmaxf(m0_, m1);
-                lse[mt][r] = mx + logf(s0 * expf(m0_ - mx) + s1 * expf(m1 - mx));   // log_softmax = x - logsumexp(x)
+                lse[mt][r] = mx + __logf(s0 * __expf(m0_ - mx) + s1 * __expf(m1 - mx));   // log_softmax = x - logsumexp(x)
             }
     }
+    // The rows leave through LDS so that every store instruction writes 16 bytes per lane and 1 KiB contiguous per wave (a row of
+    // 412 floats is 103 float4, rows are 16-byte aligned): straight from the accumulators a lane owns one column of four rows, i.e.
+    // 4-byte stores in 64-byte pieces, and the epilogue was store-issue bound (~50 us per workgroup against ~4 us of MFMA).
+    // The wave's 16 x 208 sub-tile of row tile mt goes to its own 13 KiB of the (now free) operand buffers.
+    float* stage = reinterpret_cast<float*>(jl_smem) + wave * (16 * 208);
+    const int ncol = min(208, P.V - wn);                       // valid columns of this wave's half (a multiple of 4 for V % 4 == 0)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+        __syncthreads();                                       // operand buffers / previous round fully consumed
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long m = m0 + wm + 16 * mt + 4 * kq + r;
-            if (m >= P.M) continue;
-            float* orow = P.out + m * P.V;
+        for (int t = 0; t < JL_NT; ++t)
 #pragma unroll
-            for (int t = 0; t < JL_NT; ++t) {
-                if (!nin[t]) continue;
-                float v = acc[mt][t][r] + bias[t];
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mt][t][r];
                 if constexpr (LSM) v -= lse[mt][r];
-                stg1_nt(orow + wn + 16 * t + i, v);
+                stage[(4 * kq + r) * 208 + 16 * t + i] = v;
             }
+        __syncthreads();
+        for (int e = lane; e < 16 * 52; e += 64) {
+            const int rr = e / 52, c4 = (e - rr * 52) * 4;
+            const long long m = m0 + wm + 16 * mt + rr;
+            if (m < P.M && c4 < ncol) stg4_nt(P.out + m * P.V + wn + c4, *reinterpret_cast<const float4*>(&stage[rr * 208 + c4]));
         }
+    }
 }

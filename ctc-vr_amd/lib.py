@@ -42,6 +42,7 @@ SIGNATURES = {
     "rnnt_joint": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rnnt_encoder_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_ctc_argmax": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32p, c_vp]),
+    "rnnt_ctc_logprobs": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp]),
     "rnnt_fbank": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32p, c_vp]),
     "rnnt_greedy_search_full": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rnnt_get_att_cache": (c_i32, [c_vp, c_i32, c_vp, c_i32p, c_vp]),
@@ -254,6 +255,9 @@ class RnntEngine:
         self._chk(self.lib.rnnt_ctc_argmax(self.ctx, fbank_ptr, _np_ptr(lens), B, T, _np_ptr(ids), ctypes.byref(t), stream), "rnnt_ctc_argmax")
         self.n_streams = 0
         return ids
+
+    def ctc_logprobs(self, enc_ptr, rows, out_ptr, stream=None):
+        self._chk(self.lib.rnnt_ctc_logprobs(self.ctx, enc_ptr, rows, out_ptr, stream), "rnnt_ctc_logprobs")
 
     def greedy_search_full(self, fbank_ptr, lens, B, T, n_steps=64, stream=None):
         """Offline greedy search over the full-context encoder (model/component/transducer.py:22-70) -> list of token lists."""

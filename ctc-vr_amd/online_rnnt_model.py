@@ -336,6 +336,74 @@ class OnlineRNNTModel:
             return self.streaming_inference(audios, audio_lens)
         return self.greedy_search_full(audios, audio_lens), None, None
 
+    def prefix_beam_search(self, audios: torch.Tensor, audio_lens: torch.Tensor, beam_size: int = 5, ctc_weight: float = 0.3,
+                           transducer_weight: float = 0.7):
+        """WeNet prefix beam search (wenet/transducer/search/prefix_beam_search.py:42-148) on the full-context encoder
+        (decoding_chunk_size=-1), B = 1: at most one symbol per frame, CTC shallow fusion, prefix merging with log_add.
+        Device: encoder (rnnt_encoder_full), CTC posteriors (rnnt_ctc_logprobs), one predictor step and one joint + log_softmax
+        per frame for all hypotheses (rnnt_predictor_step, rnnt_joint).  Host: the fusion / top-k (float32, torch CPU ops as
+        in the reference), candidate order, log_add merge (Python double, the LIST form the reference's call site was written
+        for: its vendored log_add(*args) raises TypeError on a merge), stable sort, truncation.
+        Returns [(tokens incl. the leading blank, score)], best first."""
+        import math
+        self._require_loaded()
+        assert audios.size(0) == 1, "prefix_beam_search is batch-1 in the reference (:58)"
+        eng, dev, V = self._engine, self.device, self.vocab_size
+        x = audios.to(dev, torch.float32).contiguous()
+        T = x.size(1)
+        tq = ((T - 3) // 2 + 1 - 3) // 2 + 1
+        s = _stream_ptr()
+        enc = torch.empty(1, tq, 256, device=dev)
+        eng.encoder_full(x.data_ptr(), np.asarray([int(audio_lens[0])], np.int32), 1, T, enc.data_ptr(), s)
+        n1 = (int(audio_lens[0]) - 1) // 2
+        n_valid = (n1 - 1) // 2                                  # frames the padding mask keeps (subsampling.py:228)
+        ctc_dev = torch.empty(tq, V, device=dev)
+        eng.ctc_logprobs(enc.data_ptr(), tq, ctc_dev.data_ptr(), s)
+        ctc = ctc_dev.cpu()
+        hyps, scores = [[self.blank_id]], [0.0]
+        h = torch.zeros(1, 256, device=dev)
+        c = torch.zeros(1, 256, device=dev)
+
+        def log_add(args):
+            if all(a == -float("inf") for a in args):
+                return -float("inf")
+            a_max = max(args)
+            return a_max + math.log(sum(math.exp(a - a_max) for a in args))
+        for i in range(min(tq, n_valid) if n_valid > 0 else tq):
+            n = len(hyps)
+            tok = torch.tensor([hy[-1] for hy in hyps], dtype=torch.int32, device=dev)
+            pred, h2, c2 = torch.empty(n, 256, device=dev), torch.empty(n, 256, device=dev), torch.empty(n, 256, device=dev)
+            eng.predictor_step(tok.data_ptr(), h.data_ptr(), c.data_ptr(), n, pred.data_ptr(), h2.data_ptr(), c2.data_ptr(), s)
+            lp_dev = torch.empty(1, 1, n, V, device=dev)
+            eng.joint(enc[:, i:i + 1].contiguous().data_ptr(), pred.data_ptr(), 1, 1, n, 1, lp_dev.data_ptr(), s)
+            logp = lp_dev.view(n, V).cpu()
+            logp = torch.log(torch.add(transducer_weight * torch.exp(logp), ctc_weight * torch.exp(ctc[i].unsqueeze(0))))   # :99-101
+            top_lp, top_ix = logp.topk(beam_size)                                                                            # :104
+            sc = torch.add(torch.tensor(scores).unsqueeze(1), top_lp)                                                        # :105 (float32)
+            cand = []                                            # [tokens, score, state row in cat(h, h2)]
+            for j in range(n):
+                for t in range(beam_size):
+                    if int(top_ix[j, t]) == self.blank_id:
+                        cand.append([list(hyps[j]), sc[j, t].item(), j])
+                    else:
+                        cand.append([list(hyps[j]) + [int(top_ix[j, t])], sc[j, t].item(), n + j])
+            fused = [cand[0]]
+            for cnd in cand[1:]:
+                for f in fused:
+                    if cnd[0] == f[0]:
+                        f[1] = log_add([f[1], cnd[1]])
+                        break
+                else:
+                    fused.append(cnd)
+            fused.sort(key=lambda v: v[1], reverse=True)
+            fused = fused[:beam_size]
+            rows = torch.tensor([f[2] for f in fused], device=dev)
+            h = torch.cat([h, h2], 0).index_select(0, rows).contiguous()
+            c = torch.cat([c, c2], 0).index_select(0, rows).contiguous()
+            hyps, scores = [f[0] for f in fused], [f[1] for f in fused]
+        self._prefix_states = (h, c)
+        return list(zip(hyps, scores))
+
     def greedy_search_full(self, audios, audio_lens, n_steps: int = 64):
         """basic_greedy_search over the deterministic full-context encoder; audios [B,T,80] with B <= max_streams,
         T <= max_chunk_frames, ((T-3)//2+1-3)//2+1 <= max_enc_frames.  Invalidates the streaming state."""
@@ -431,6 +499,34 @@ class StreamingBatch:
         if decode:
             self.engine.greedy_decode(s)
             self.engine.frames_consume(s)
+
+    def decode_script_ragged(self, audios: torch.Tensor, audio_lens, chunk_frames: int, pipelined: bool = True) -> List[List[int]]:
+        """Greedy loop of online_rnnt_decode.py:81-117 for a PADDED batch of utterances of different lengths (utils/utils.py:29-50
+        pads them; online_rnnt_eval.py:86-94 decodes each with its own audio_lens): stream b is decoded over its own
+        audio_lens[b] frames with its own chunk plan (tail-merge rule, < 7-frame skip), so its tokens equal its B = 1 result.
+        The context advances its streams in lock step, so the batch is run as LENGTH CLASSES: streams with equal lengths share
+        one whole-utterance call (same chunk plan), classes follow one another on the same context.  A batch of equal lengths is
+        one call; n different lengths are n calls -- per-stream masking inside one launch is not implemented."""
+        assert audios.is_cuda and audios.dtype == torch.float32 and audios.size(0) == self.n
+        lens = [int(v) for v in (audio_lens.tolist() if hasattr(audio_lens, "tolist") else audio_lens)]
+        assert len(lens) == self.n and max(lens) <= audios.size(1) and min(lens) >= 0
+        out: List[Optional[List[int]]] = [None] * self.n
+        n_all = self.n
+        try:
+            for T_ in sorted(set(lens), reverse=True):
+                idx = [b for b in range(n_all) if lens[b] == T_]
+                if T_ < 7:                                   # shorter than the conv front-end's receptive field: skipped (:356-359)
+                    for b in idx:
+                        out[b] = []
+                    continue
+                sub = audios[torch.tensor(idx, device=audios.device), :T_, :].contiguous()
+                self.n = len(idx)
+                toks = self.decode_script(sub, chunk_frames, per_chunk_decode=not pipelined, pipelined=pipelined)
+                for b, t in zip(idx, toks):
+                    out[b] = t
+        finally:
+            self.n = n_all
+        return out
 
     def decode_script(self, audios: torch.Tensor, chunk_frames: int, per_chunk_decode: bool = True, pipelined: bool = False) -> List[List[int]]:
         """Greedy loop of online_rnnt_decode.py:81-117 over [B,T,80] equal-length utterances.

@@ -186,6 +186,11 @@ int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens
 int rnnt_ctc_argmax(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B, int32_t T,
                     int32_t* ids_host, int32_t* frames_out, void* stream);
 
+/* OnlineCTC.log_softmax (model/online_rnnt_model.py:34-35) on encoder frames already on the device: out_dev [rows, vocab] =
+ * log_softmax(ctc_lo(enc_dev [rows, 256])).  The CTC term of the WeNet prefix beam search (wenet/transducer/search/
+ * prefix_beam_search.py:66,99-101), whose frame loop runs in the facade over rnnt_encoder_full / rnnt_predictor_step / rnnt_joint. */
+int rnnt_ctc_logprobs(rnnt_ctx* ctx, const float* enc_dev, int32_t rows, float* out_dev, void* stream);
+
 /* Offline greedy search: basic_greedy_search (model/component/transducer.py:22-70) behind
  * OnlineRNNTModel.forward(audios, audio_lens) of a non-streaming model (model/online_rnnt_model.py:234-235,268):
  * full-context encoder + per-utterance greedy loop over its valid frames, <= n_steps symbols per frame (reference

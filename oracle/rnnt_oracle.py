@@ -255,6 +255,57 @@ def ctc_greedy_search_full(sd: SD, xs: Tensor, xs_lens: Tensor, blank: int) -> L
     return hyps
 
 
+def _log_add(args: List[float]) -> float:
+    """wenet.utils.common.log_add as its prefix-beam-search call site uses it: stable log-sum-exp of a LIST of Python floats
+    (wenet/transducer/search/prefix_beam_search.py:136-138 passes one list; the vendored common.py:302-310 declares *args, so the
+    reference raises TypeError whenever two prefixes merge -- the list form is upstream WeNet's and the only one the call fits)."""
+    if all(a == -float("inf") for a in args):
+        return -float("inf")
+    a_max = max(args)
+    return a_max + math.log(sum(math.exp(a - a_max) for a in args))
+
+
+def prefix_beam_search_full(sd: SD, xs: Tensor, xs_lens: Tensor, blank: int, beam_size: int = 5, ctc_weight: float = 0.3,
+                            transducer_weight: float = 0.7):
+    """PrefixBeamSearch.prefix_beam_search (wenet/transducer/search/prefix_beam_search.py:42-148) on the full-context encoder
+    (decoding_chunk_size=-1), B = 1: one symbol at most per frame; per frame every hypothesis runs one predictor step on its last
+    token, joint + log_softmax, shallow fusion with the CTC posterior log(tw * exp(logp) + cw * exp(ctc[i])) (:99-101), top-beam
+    per hypothesis (:104), blank keeps hypothesis and predictor state, a token extends both (:110-126), equal prefixes are merged
+    with log_add keeping the first one's state (:128-141), stable sort by score, truncate (:144-145).
+    Returns [(tokens incl. the leading blank, score, [h, c])]."""
+    assert xs.size(0) == 1
+    enc, _ = encoder_full(sd, xs, xs_lens)
+    ctc = torch.log_softmax(F.linear(enc, sd["ctc_head.ctc_lo.weight"], sd["ctc_head.ctc_lo.bias"]), dim=2).squeeze(0)
+    beam = [([blank], 0.0, predictor_init_state(1))]
+    for i in range(enc.size(1)):
+        toks = torch.tensor([b[0][-1] for b in beam], dtype=torch.long)
+        state = [torch.cat([b[2][0] for b in beam], 1), torch.cat([b[2][1] for b in beam], 1)]
+        scores = torch.tensor([b[1] for b in beam])                                     # float32, as torch.tensor(list of floats)
+        pred, new_state = predictor_step(sd, toks.view(-1, 1), state)                    # [N,1,256]
+        logp = joint(sd, enc[:, i:i + 1, :], pred).log_softmax(dim=-1).squeeze(1).squeeze(1)   # [N, V]
+        logp = torch.log(torch.add(transducer_weight * torch.exp(logp), ctc_weight * torch.exp(ctc[i].unsqueeze(0))))
+        top_lp, top_ix = logp.topk(beam_size)
+        sc = torch.add(scores.unsqueeze(1), top_lp)
+        cand = []
+        for j, (hyp, _, st) in enumerate(beam):
+            for t in range(beam_size):
+                if int(top_ix[j, t]) == blank:
+                    cand.append([list(hyp), sc[j, t].item(), st])
+                else:
+                    cand.append([list(hyp) + [int(top_ix[j, t])], sc[j, t].item(), [new_state[0][:, j:j + 1], new_state[1][:, j:j + 1]]])
+        fused = [cand[0]]
+        for c in cand[1:]:
+            for f in fused:
+                if c[0] == f[0]:
+                    f[1] = _log_add([f[1], c[1]])
+                    break
+            else:
+                fused.append(c)
+        fused.sort(key=lambda v: v[1], reverse=True)
+        beam = [(f[0], f[1], f[2]) for f in fused[:beam_size]]
+    return beam
+
+
 # --------------------------------------------------------------------------------------
 # predictor / joint
 # --------------------------------------------------------------------------------------

@@ -334,7 +334,20 @@ def gen_ctc():
 def gen_prefix():
     """WeNet prefix beam search (wenet/transducer/search/prefix_beam_search.py:42-148) run as the reference class on the model's
     own encoder / predictor / joint / CTC head, full context (decoding_chunk_size=-1), B = 1."""
+    import math
+    import wenet.transducer.search.prefix_beam_search as pbs_mod
     from wenet.transducer.search.prefix_beam_search import PrefixBeamSearch
+
+    # The reference's call site is `log_add([a, b])` (prefix_beam_search.py:136-138) but the vendored wenet/utils/common.py:302-310
+    # declares `log_add(*args)`: max() then returns the list and `a - a_max` raises TypeError whenever two prefixes merge, i.e. on
+    # practically every utterance.  The generator binds the NAME log_add inside that module to the list form the call was written
+    # for (upstream WeNet's signature, same arithmetic); no other line of the reference is touched.
+    def log_add_list(args):
+        if all(a == -float("inf") for a in args):
+            return -float("inf")
+        a_max = max(args)
+        return a_max + math.log(sum(math.exp(a - a_max) for a in args))
+    pbs_mod.log_add = log_add_list
     for seed, frames, beam in ((0, 240, 4), (1, 171, 5)):
         net = build(seed, 16)
         x = torch.from_numpy(T.synth_fbank(1, frames, seed=55 + seed))

@@ -387,7 +387,8 @@ def test_ctc_greedy_search_matches_reference(seed, np_state_dict, numerics):
         want.append(g["hyp_tokens"][o:o + c].tolist())
         o += c
     assert got == want and len(got[0]) > 0
-    ids = m._engine.ctc_argmax(x.cuda().contiguous().data_ptr(), lens.numpy(), 2, 300, torch.cuda.current_stream().cuda_stream)
+    xd = x.cuda().contiguous()                      # keep the tensor alive across the call
+    ids = m._engine.ctc_argmax(xd.data_ptr(), lens.numpy().astype(np.int32), 2, 300, torch.cuda.current_stream().cuda_stream)
     valid = g["mask"][:, 0, :]
     assert np.array_equal(ids[valid], g["ids"][valid])
     assert float(g["min_margin"]) > 1e-3
@@ -548,3 +549,51 @@ def test_large_vocabulary_paths():
         assert [h.tokens for h in hb] == [h.tokens for h in ob]
         assert max(abs(p.log_prob - q.log_prob) for p, q in zip(hb, ob)) < 2e-3
     assert any(t >= 512 for h in hb for t in h.tokens)
+
+
+def test_ragged_batch_equals_single_stream_references(np_state_dict, numerics):
+    """Eight utterances of different lengths in one padded batch (utils/utils.py:29-50; online_rnnt_eval.py:86-94 decodes each with
+    its own audio_lens): every stream's tokens equal its own B = 1 golden / oracle result -- three example1.pt utterances with
+    reference goldens (521, 160, 648 frames), a duplicate length (two streams share one class) and synthetic lengths down to one
+    below the 7-frame minimum."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    ex = ex_inputs()
+    syn = torch.from_numpy(T.synth_fbank(5, 1000))
+    utts = [ex["ex0"][0], ex["ex6"][0], ex["ex12"][0], syn[0, :1000], syn[1, :333], syn[2, :160], syn[3, :47], syn[4, :6]]
+    lens = [u.shape[0] for u in utts]
+    x = torch.zeros(len(utts), max(lens), 80)
+    for b, u in enumerate(utts):
+        x[b, :lens[b]] = u
+    sb = StreamingBatch(np_state_dict(0), len(utts), max_chunk_frames=48, max_cache_frames=256, max_enc_frames=256)
+    got = sb.decode_script_ragged(x.cuda().contiguous(), torch.tensor(lens), 16)
+    assert got[1] == load_golden("stream_ex6_c16_s0.npz")["tokens"].tolist()        # reference golden (160 frames, chunk 16, seed 0)
+    assert got[3] == load_golden("stream_syn0_c16_s0.npz")["tokens"].tolist()       # reference golden (1000 frames)
+    sd = O.to_torch_sd(np_state_dict(0))
+    for b, u in enumerate(utts):
+        want, _, _ = O.decode_script_greedy(sd, u[None], 16) if lens[b] >= 7 else ([], None, None)
+        assert got[b] == want, (b, lens[b])
+    assert got[7] == [] and len(got[0]) > 0 and len(got[6]) >= 0
+    assert sb.decode_script_ragged(x.cuda().contiguous(), torch.tensor(lens), 16, pipelined=False) == got
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_prefix_beam_search_matches_reference(seed, np_state_dict, numerics):
+    """WeNet prefix beam search (CTC-fused, one symbol per frame, log_add prefix merge) on the full-context encoder
+    against the reference class itself (golden prefix_beam_seed*.npz): hypotheses exact, scores within 2e-3 (double sums of fp32
+    log-probs), final LSTM h of every hypothesis within 1e-3."""
+    from ctc_vr_amd.online_rnnt_model import OnlineRNNTModel
+    g = load_golden(f"prefix_beam_seed{seed}.npz")
+    frames = int(g["frames"])
+    m = OnlineRNNTModel(input_dim=80, hidden_dim=256, vocab_size=T.VOCAB, blank_id=T.BLANK, max_streams=8, max_chunk_frames=256,
+                        max_cache_frames=128, max_enc_frames=128, max_beam=0)
+    m.load_state_dict(np_state_dict(seed))
+    x = torch.from_numpy(T.synth_fbank(1, frames, seed=int(g["fbank_seed"])))
+    beam = m.prefix_beam_search(x, torch.tensor([frames]), beam_size=int(g["beam"]))
+    want, o = [], 0
+    for c in g["hyp_counts"].tolist():
+        want.append(g["hyp_tokens"][o:o + c].tolist())
+        o += c
+    assert [b[0] for b in beam] == want
+    assert max(abs(b[1] - s) for b, s in zip(beam, g["scores"])) < 2e-3
+    assert maxdiff(m._prefix_states[0].cpu().numpy()[None], g["h"]) < LOGIT_TOL

@@ -203,3 +203,21 @@ def test_ctc_head_matches_reference(seed):
     valid = g["mask"][:, 0, :]
     assert np.array_equal(lp.argmax(2).numpy()[valid], g["ids"][valid])
     assert np.abs(lp[:, :8].numpy() - g["logp_first8"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_prefix_beam_search_matches_reference(seed):
+    """oracle prefix_beam_search_full vs the reference's PrefixBeamSearch.prefix_beam_search run on the model's own encoder /
+    predictor / joint / CTC head (golden prefix_beam_seed*.npz; the generator rebinds the name log_add in that module to the list
+    form its call site uses, see gen_golden.py): hypotheses exact, scores to 1e-4, final predictor states to 1e-4."""
+    g = load_golden(f"prefix_beam_seed{seed}.npz")
+    sd = O.to_torch_sd(T.make_state_dict(seed))
+    x = torch.from_numpy(T.synth_fbank(1, int(g["frames"]), seed=int(g["fbank_seed"])))
+    beam = O.prefix_beam_search_full(sd, x, torch.tensor([int(g["frames"])]), T.BLANK, beam_size=int(g["beam"]))
+    want, o = [], 0
+    for c in g["hyp_counts"].tolist():
+        want.append(g["hyp_tokens"][o:o + c].tolist())
+        o += c
+    assert [b[0] for b in beam] == want
+    assert max(abs(b[1] - s) for b, s in zip(beam, g["scores"])) < 1e-4
+    assert np.abs(torch.cat([b[2][0] for b in beam], 1).numpy() - g["h"]).max() < 1e-4
