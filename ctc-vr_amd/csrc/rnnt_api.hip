@@ -118,6 +118,14 @@ struct rnnt_ctx {
     std::vector<std::array<int, 13>> wf_lstart;
     std::vector<int> wf_sc_first, wf_key;
     std::vector<hipEvent_t> ev_pool;
+    // layer-major schedule (host_lm.hip.inc): activations over all B*F rows of a call, per-layer linear post-GLU rows, one
+    // subsampling slab, attention block table (reused while the plan and the entry state stay the same)
+    int use_lm = 1;                            // RNNT_LM=0: wavefront schedule for every whole-utterance call
+    float *lm_h = nullptr, *lm_q = nullptr, *lm_a = nullptr, *lm_d = nullptr, *lm_g = nullptr, *lm_y1 = nullptr, *lm_y2 = nullptr;
+    size_t lm_y1_cap = 0, lm_y2_cap = 0, lm_blocks_cap = 0;
+    LmBlock* lm_blocks = nullptr;
+    std::vector<LmBlock> lm_blocks_host;
+    std::vector<int> lm_key;
     // native beam bookkeeping (rnnt_beam_advance): per stream, hypotheses in device-row order
     struct Hyp { std::vector<int> tokens; double log_prob; };
     std::vector<std::vector<Hyp>> beams;
@@ -139,6 +147,7 @@ struct rnnt_ctx {
 };
 
 #include "host_launch.hip.inc"
+#include "host_lm.hip.inc"
 
 extern "C" {
 #include "api_lifecycle.hip.inc"

@@ -11,7 +11,7 @@
 // wavefront path subsamples several equal-length chunks of every stream in one launch.
 __global__ void conv1_relu(const float* __restrict__ x, const float* __restrict__ w1t /*[9][256]*/,
                            const float* __restrict__ b1, float* __restrict__ y1, int B, int T, int t1,
-                           const int* __restrict__ starts, int n_chunks) {
+                           const int* __restrict__ starts, int n_chunks, int b_major) {
     const long long n = (long long)n_chunks * B * t1 * RNNT_F1 * RNNT_D;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(id & 255);
@@ -20,7 +20,9 @@ __global__ void conv1_relu(const float* __restrict__ x, const float* __restrict_
         r /= RNNT_F1;
         const int t = (int)(r % t1);
         const int v = (int)(r / t1);
-        const int cidx = v / B, b = v - cidx * B;
+        // virtual stream order: chunk-major (v = c*B + b) or stream-major (v = b*n_chunks + c: a stream's chunks are consecutive,
+        // so its frames come out of the embed Linear in time order -- the layer-major encoder's row layout)
+        const int cidx = b_major ? v % n_chunks : v / B, b = b_major ? v / n_chunks : v - cidx * B;
         const int st0 = starts ? starts[cidx] : 0;
         const float* xp = x + ((long long)b * T + st0 + 2 * t) * RNNT_IDIM + 2 * f;
         float acc = b1[c];

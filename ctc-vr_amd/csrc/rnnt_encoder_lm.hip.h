@@ -1,0 +1,217 @@
+// Layer-major whole-utterance encoder kernels (rnnt_encoder_chunks when every chunk of the call is already in HBM).
+// Part of rnnt_kernels.hip.h (include that umbrella, not this file).
+//
+// Layer l of chunk c needs layer l-1 of the SAME chunk (per frame) and, from layer l's own earlier chunks, only their K/V rows
+// and post-GLU conv rows -- both functions of layer l's INPUT, not of its attention output (encoder.py:274-288,
+// convolution.py:122-130).  So a whole layer can run over all chunks of the call at once: every per-frame contraction becomes
+// one GEMM over M = streams x frames rows, and what remains chunk-aware is (1) attention, where a query of chunk c sees exactly
+// the keys the chunk-by-chunk loop would have cached for it, at that chunk's positional window, and (2) the causal depthwise
+// conv, which is simply a causal conv over the utterance with the stream's 30-row left context.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// rel_attention_lm: RelPositionMultiHeadedAttention scores / softmax / PV (attention.py:400-418,170-177) for ALL chunks of a
+// call.  A "unit" is up to 4 consecutive query frames of one chunk; its keys are the absolute cache rows
+// [kv_start, kv_start + T2) of the stream and the positional row of cache row a is a + pshift (pshift = pos_start - kv_start:
+// encoder.py:257 rebuilt per chunk, no rel_shift).  A workgroup = LM_NW waves = LM_NW units of consecutive chunks and one
+// (stream, head): K / V / positional rows are staged ONCE per 64-key tile for all its units (the chunk-by-chunk kernels re-read
+// the whole cache for every chunk: 9.3 GB per 64 x 10 s batch; here ~1/8 of that).  Scores with lane = key, online softmax per
+// unit, PV with lane = d.  The units' positional windows differ by a few rows: the positional tile carries LM_PEXT extra rows.
+//   q, out  [B*F][256] stream-major rows (b*F + f);  kc, vc [B][kv_stride][256];  ptab [5000][256] of this layer
+// grid = (B*H, n_blocks), block = 64*LM_NW, dynamic LDS = LM_ATT_LDS bytes.
+// ------------------------------------------------------------------------------------------------
+#define LM_NW 8
+#define LM_PEXT 16
+struct LmUnit { int f0, nq, kv_start, T2, pshift; };
+struct LmBlock {
+    int n_units, amin, amax, pmin;     // key rows [amin, amax) cover every unit; pmin = smallest pshift
+    LmUnit u[LM_NW];
+};
+struct LmAttnP {
+    const float* q;
+    const float* kc;
+    const float* vc;
+    const float* ptab;
+    const float* bias_u;
+    const float* bias_v;
+    float* out;
+    const LmBlock* blocks;
+    int F;
+    long long kv_stride;
+};
+#define LM_ATT_LDS ((64 * ATT_LD + (64 + LM_PEXT) * ATT_LD + 64 * RNNT_DK + 3 * LM_NW * 4 * RNNT_DK) * 4)
+__global__ __launch_bounds__(64 * LM_NW) void rel_attention_lm(LmAttnP P) {
+    extern __shared__ __attribute__((aligned(16))) float lm_smem[];
+    float* Ks = lm_smem;                              // [64][ATT_LD]
+    float* Ps = Ks + 64 * ATT_LD;                     // [64 + PEXT][ATT_LD]
+    float* Vs = Ps + (64 + LM_PEXT) * ATT_LD;         // [64][64]
+    float* Qu = Vs + 64 * RNNT_DK;                    // [NW][4][64]
+    float* Qv = Qu + LM_NW * 4 * RNNT_DK;
+    float* Pm = Qv + LM_NW * 4 * RNNT_DK;             // [NW][4][64]
+    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const LmBlock* __restrict__ blk = P.blocks + blockIdx.y;
+    const int n_units = ldgi(&blk->n_units), amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
+    int f0 = 0, nq = 0, ks = 0, ke = 0, prel = 0;
+    if (wave < n_units) {
+        f0 = ldgi(&blk->u[wave].f0); nq = ldgi(&blk->u[wave].nq);
+        ks = ldgi(&blk->u[wave].kv_start); ke = ks + ldgi(&blk->u[wave].T2);
+        prel = ldgi(&blk->u[wave].pshift) - pmin;     // 0 .. LM_PEXT
+    }
+    for (int e = tid; e < LM_NW * 4 * RNNT_DK; e += 64 * LM_NW) {
+        const int w = e >> 8, iq = (e >> 6) & 3, d = e & 63;
+        float qq = 0.f;
+        if (w < n_units && iq < ldgi(&blk->u[w].nq))
+            qq = ldg1(P.q + ((long long)b * P.F + ldgi(&blk->u[w].f0) + iq) * RNNT_D + h * RNNT_DK + d);
+        Qu[e] = qq + ldg1(P.bias_u + h * RNNT_DK + d);
+        Qv[e] = qq + ldg1(P.bias_v + h * RNNT_DK + d);
+    }
+    float mrun[4], lrun[4], o[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { mrun[s] = -INFINITY; lrun[s] = 0.f; o[s] = 0.f; }
+    const float* kbase = P.kc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
+    const float* vbase = P.vc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
+    const float* pbase = P.ptab + h * RNNT_DK;
+    for (int a0 = amin; a0 < amax; a0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 16; e += 64 * LM_NW) {
+            const int r = e >> 4, c4 = e & 15;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (a0 + r < amax) {
+                kv = ldg4(kbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
+                vv = ldg4(vbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(&Ks[r * ATT_LD + c4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[r * RNNT_DK + c4 * 4]) = vv;
+        }
+        for (int e = tid; e < (64 + LM_PEXT) * 16; e += 64 * LM_NW) {
+            const int r = e >> 4, c4 = e & 15;
+            const int pr = a0 + pmin + r;
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr >= 0 && pr < RNNT_PE_LEN) pv = ldg4(pbase + (long long)pr * RNNT_D + c4 * 4);
+            *reinterpret_cast<float4*>(&Ps[r * ATT_LD + c4 * 4]) = pv;
+        }
+        __syncthreads();
+        if (nq == 0 || a0 >= ke || a0 + 64 <= ks) continue;        // wave-uniform: this unit has no key in the tile
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* krow = Ks + lane * ATT_LD;
+        const float* prow = Ps + (lane + prel) * ATT_LD;
+        const float* qu = Qu + wave * 4 * RNNT_DK;
+        const float* qv = Qv + wave * 4 * RNNT_DK;
+#pragma unroll 4
+        for (int dc = 0; dc < 16; ++dc) {
+            const float4 k4 = *reinterpret_cast<const float4*>(krow + dc * 4);
+            const float4 p4 = *reinterpret_cast<const float4*>(prow + dc * 4);
+#pragma unroll
+            for (int iq = 0; iq < 4; ++iq) {
+                const float4 u4 = *reinterpret_cast<const float4*>(qu + iq * RNNT_DK + dc * 4);
+                const float4 v4 = *reinterpret_cast<const float4*>(qv + iq * RNNT_DK + dc * 4);
+                float t = s[iq];
+                t = fmaf(u4.x, k4.x, t); t = fmaf(u4.y, k4.y, t); t = fmaf(u4.z, k4.z, t); t = fmaf(u4.w, k4.w, t);
+                t = fmaf(v4.x, p4.x, t); t = fmaf(v4.y, p4.y, t); t = fmaf(v4.z, p4.z, t); t = fmaf(v4.w, p4.w, t);
+                s[iq] = t;
+            }
+        }
+        const int a = a0 + lane;
+        const bool valid = a >= ks && a < ke;
+        float alpha[4];
+        float* pm = Pm + wave * 4 * 64;
+#pragma unroll
+        for (int iq = 0; iq < 4; ++iq) {
+            const float sc = valid ? s[iq] * 0.125f : -INFINITY;
+            const float mnew = fmaxf(mrun[iq], wave_max(sc));     // finite: the tile holds at least one valid key
+            const float pe_ = valid ? expf(sc - mnew) : 0.f;
+            alpha[iq] = expf(mrun[iq] - mnew);                    // first tile: exp(-inf) = 0
+            lrun[iq] = lrun[iq] * alpha[iq] + wave_sum(pe_);
+            mrun[iq] = mnew;
+            pm[iq * 64 + lane] = pe_;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // pm rows are private to the wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int iq = 0; iq < 4; ++iq) o[iq] *= alpha[iq];
+        const int j0 = max(ks - a0, 0), j1 = min(ke - a0, 64);
+        for (int j = j0; j < j1; ++j) {
+            const float vj = Vs[j * RNNT_DK + lane];
+#pragma unroll
+            for (int iq = 0; iq < 4; ++iq) o[iq] = fmaf(pm[iq * 64 + j], vj, o[iq]);
+        }
+    }
+#pragma unroll
+    for (int iq = 0; iq < 4; ++iq)
+        if (iq < nq) stg1(P.out + ((long long)b * P.F + f0 + iq) * RNNT_D + h * RNNT_DK + lane, o[iq] / lrun[iq]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// lm_ctx_in: the 30-row left context of every layer's linear post-GLU buffer <- the stream's ring rows before `pos`
+// (a fresh stream's ring holds GLU(b_pw1): the zero pad goes through the biased pointwise conv, convolution.py:122-124,138).
+// g_lin [L][B][gs][256], ring [L][Bmax][cap][256].
+// ------------------------------------------------------------------------------------------------
+__global__ void lm_ctx_in(const float* __restrict__ ring, float* __restrict__ g_lin, int B, int Bmax, int cap, int gs, int pos) {
+    const long long n = (long long)RNNT_L * B * RNNT_LORDER * RNNT_D;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 255);
+        long long r = id >> 8;
+        const int i = (int)(r % RNNT_LORDER);
+        r /= RNNT_LORDER;
+        const int b = (int)(r % B), l = (int)(r / B);
+        const int row = (pos - RNNT_LORDER + i + cap * 64) % cap;
+        g_lin[(((long long)l * B + b) * gs + i) * RNNT_D + c] = ldg1(ring + (((long long)l * Bmax + b) * cap + row) * RNNT_D + c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dwconv_lm: causal depthwise conv k=31 + BatchNorm(eval) + SiLU (convolution.py:142-145) over the linear post-GLU rows of one
+// layer, g [B][gs][256] with 30 left-context rows first; frame f of stream b = row 30 + f.  One thread = one channel and
+// LM_FB consecutive frames (sliding window in registers: 38 loads for 8 outputs); taps summed in the order of dwconv_bn_silu.
+// Also leaves the stream state the chunk-by-chunk path would leave: the last `cap` frames' post-GLU rows and conv-module
+// input rows in the two rings at (pos + f) % cap.
+// ------------------------------------------------------------------------------------------------
+#define LM_FB 8
+struct DwLmP {
+    const float* g;
+    const float* wdw_t;
+    const float* bdw;
+    const float* bn_s;
+    const float* bn_t;
+    float* out;            // [B*F][256]
+    const float* xres;     // [B*F][256] conv-module input (before norm_conv)
+    float* gring;          // [Bmax][cap][256] of this layer
+    float* xring;
+    int B, F, gs, cap, pos;
+};
+__global__ void dwconv_lm(DwLmP P) {
+    const int nfb = (P.F + LM_FB - 1) / LM_FB;
+    const long long n = (long long)P.B * nfb * RNNT_D;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < n; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 255);
+        const int r = (int)(id >> 8);
+        const int b = r / nfb, f0 = (r - b * nfb) * LM_FB;
+        const float* gb = P.g + ((long long)b * P.gs + f0) * RNNT_D + c;
+        float win[LM_FB + RNNT_LORDER];
+#pragma unroll
+        for (int i = 0; i < LM_FB + RNNT_LORDER; ++i) win[i] = (f0 + i < P.F + RNNT_LORDER) ? ldg1(gb + (long long)i * RNNT_D) : 0.f;
+        float w[RNNT_KDW];
+#pragma unroll
+        for (int k = 0; k < RNNT_KDW; ++k) w[k] = ldg1(P.wdw_t + k * RNNT_D + c);
+        const float bd = ldg1(P.bdw + c), bs = ldg1(P.bn_s + c), bt = ldg1(P.bn_t + c);
+#pragma unroll
+        for (int j = 0; j < LM_FB; ++j) {
+            const int f = f0 + j;
+            if (f >= P.F) break;
+            float acc = bd;
+#pragma unroll
+            for (int k = 0; k < RNNT_KDW; ++k) acc = fmaf(w[k], win[j + k], acc);
+            float v = acc * bs + bt;
+            v = v * sigmoidf_(v);
+            const long long m = (long long)b * P.F + f;
+            stg1(P.out + m * RNNT_D + c, v);
+            if (f >= P.F - P.cap) {
+                const long long rr = ((long long)b * P.cap + (P.pos + f) % P.cap) * RNNT_D + c;
+                stg1(P.gring + rr, win[j + RNNT_LORDER]);
+                stg1(P.xring + rr, ldg1(P.xres + m * RNNT_D + c));
+            }
+        }
+    }
+}

@@ -4,6 +4,7 @@
 #include "rnnt_gemm.hip.h"
 #include "rnnt_gemm_bf.hip.h"
 #include "rnnt_encoder.hip.h"
+#include "rnnt_encoder_lm.hip.h"
 #include "rnnt_decode.hip.h"
 #include "rnnt_frontend.hip.h"
 #include "rnnt_beam.hip.h"
