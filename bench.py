@@ -47,6 +47,14 @@ def sub_len(t):
 
 def site_kernel(site, mode):
     bf = mode != "fp32"
+    gk = "gemm_bf" if bf else "gemm_ns"
+    lm = os.environ.get("RNNT_LM", "1") != "0"          # layer-major schedule: one launch per layer over all B*F rows
+    if lm:
+        return {"conv1": "conv1_relu", "conv2": f"{gk} (conv2 implicit GEMM, all equal-length chunks in one launch)", "embed": f"{gk} (embed Linear)",
+                "ffn1": f"{gk} (ffn w_1 + LayerNorm prologue + SiLU, M = B*F)", "ffn2": f"{gk} (ffn w_2 + half-step residual, M = B*F)",
+                "qkv": f"{gk} x3 (linear_q/k/v + LayerNorm prologue, K/V rows into the cache)", "attn_out": f"{gk} (linear_out + residual)",
+                "pw1": f"{gk} (pointwise_conv1 + LayerNorm prologue + GLU)", "pw2": f"{gk} (pointwise_conv2 + residual)",
+                "attn": "rel_attention_lm (8 chunks per workgroup)", "dwconv": "dwconv_lm", "enc_proj": "joint.enc_ffn projection (+ after_norm prologue)"}.get(site, site)
     return {"conv1": "conv1_relu", "conv2": "gemm_bf<4,4> (conv2 implicit GEMM)" if bf else "gemm_ns<2,2,32> (conv2 implicit GEMM)",
             "embed": "gemm_bf (embed Linear)" if bf else "gemm_ns / gemm16 (embed Linear)",
             "block_front": "block_front (LN + FFN-macaron + LN + q/k/v, fused)", "block_back": "block_back (out-proj + conv module + FFN + LN, fused)",
@@ -56,9 +64,31 @@ def site_kernel(site, mode):
 
 
 def site_flops_bytes(site, B, plan):
-    """Algorithmic FLOPs (2*MAC) and bytes of all launches of one site in one step."""
+    """Algorithmic FLOPs (2*MAC) and bytes of all launches of one site in one step.  Layer-major schedule:
+    FLOPs are the same sums; bytes count a layer's weights, K/V rows and conv rows once per layer instead of once per chunk."""
     fl = by = 0.0
     t2 = 0
+    if os.environ.get("RNNT_LM", "1") != "0" and site not in ("conv1", "conv2", "embed", "block_front", "block_back"):
+        F = sum(sub_len(b - a) for a, b in plan)
+        M = B * F
+        kv_rows = F                                     # every frame's K/V row is written once and staged by the attention tiles
+        att_fl = 0.0
+        for i, (a, b) in enumerate(plan):
+            tq = sub_len(b - a)
+            kv = t2 + tq
+            att_fl += 2.0 * B * 4 * tq * kv * 64 * 3
+            t2 = kv if i > 0 else 0
+        per = {"ffn1": (2.0 * M * 256 * 1024, 4.0 * (M * 256 + 256 * 1024 + M * 1024), 24),
+               "ffn2": (2.0 * M * 256 * 1024, 4.0 * (M * 1024 + 256 * 1024 + 2 * M * 256), 24),
+               "qkv": (2.0 * M * 256 * 768, 4.0 * (M * 256 + 3 * 256 * 256 + 3 * M * 256), 12),
+               "attn": (att_fl, 4.0 * (2 * B * kv_rows * 256 + 2 * M * 256 + (kv_rows + len(plan)) * 256), 12),
+               "attn_out": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
+               "pw1": (2.0 * M * 256 * 512, 4.0 * (M * 256 + 512 * 256 + M * 256), 12),
+               "dwconv": (2.0 * M * 256 * 31, 4.0 * (B * (30 + F) * 256 + 2 * M * 256), 12),
+               "pw2": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
+               "enc_proj": (2.0 * M * 256 * 256, 4.0 * (2 * M * 256 + 256 * 256), 1)}
+        f, y, cnt = per[site]
+        return f * cnt, y * cnt
     for i, (a, b) in enumerate(plan):
         tq = sub_len(b - a)
         t1 = (b - a - 3) // 2 + 1
@@ -249,8 +279,7 @@ def main():
         return sb.decode_script(x, args.chunk, pipelined=True)
 
     # ---- site survey (untimed): one step per launch site -> which kernel dominates -------------------------------------------
-    fused = choice != "fp32" and os.environ.get("RNNT_FUSED", "1") != "0"
-    sites = ["conv1", "conv2", "embed", "attn", "enc_proj"] + (["block_front", "block_back"] if fused else ["ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"])
+    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
     survey = {}
     for _ in range(args.warmup):
         toks = step()

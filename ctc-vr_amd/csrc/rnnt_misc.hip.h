@@ -61,3 +61,12 @@ __global__ void debug_stream_copy(const float* __restrict__ src, float* __restri
         else stg4(dst + 4 * i, v);
     }
 }
+
+// Diagnostic (RNNT_LM_DEBUG=1): order-independent exact checksum of a buffer (sum of the 32-bit patterns), to find the first
+// launch of a schedule whose output differs between two runs.
+__global__ void debug_checksum(const float* __restrict__ p, long long n, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc += (unsigned long long)__float_as_uint(p[i]);
+    atomicAdd(out, acc);
+}

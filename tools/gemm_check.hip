@@ -1,0 +1,125 @@
+// Standalone check + timing of the split-operand GEMM variants (gemm_bf<NSPLIT,F16,MT,NT>): bitwise agreement between tile
+// shapes (same K order => identical results), run-to-run reproducibility, a CPU double reference on sampled rows, TFLOP/s.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/gemm_check tools/gemm_check.hip && tools/gemm_check
+#include "../ctc-vr_amd/csrc/rnnt_kernels.hip.h"
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+struct Prob {
+    int M, N, K; bool ln; int epi;
+    float *A, *W, *bias, *C, *R, *g, *b;
+    unsigned short *Wh, *Wl;
+    std::vector<float> hA, hW, hb, hg, hbeta;
+};
+static Prob make(int M, int N, int K, bool ln, int epi) {
+    Prob p; p.M = M; p.N = N; p.K = K; p.ln = ln; p.epi = epi;
+    std::mt19937 rng(123);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    p.hA.resize((size_t)M * K); p.hW.resize((size_t)N * K); p.hb.resize(N); p.hg.resize(K); p.hbeta.resize(K);
+    for (auto& v : p.hA) v = nd(rng);
+    for (auto& v : p.hW) v = nd(rng) * 0.06f;
+    for (auto& v : p.hb) v = nd(rng) * 0.1f;
+    for (auto& v : p.hg) v = 1.f + 0.1f * nd(rng);
+    for (auto& v : p.hbeta) v = 0.1f * nd(rng);
+    CK(hipMalloc(&p.A, p.hA.size() * 4)); CK(hipMalloc(&p.W, p.hW.size() * 4)); CK(hipMalloc(&p.bias, N * 4));
+    CK(hipMalloc(&p.C, (size_t)M * N * 4)); CK(hipMalloc(&p.R, (size_t)M * N * 4)); CK(hipMalloc(&p.g, K * 4)); CK(hipMalloc(&p.b, K * 4));
+    CK(hipMalloc(&p.Wh, p.hW.size() * 2)); CK(hipMalloc(&p.Wl, p.hW.size() * 2));
+    CK(hipMemcpy(p.A, p.hA.data(), p.hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(p.W, p.hW.data(), p.hW.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(p.bias, p.hb.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(p.g, p.hg.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(p.b, p.hbeta.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(p.R, 0, (size_t)M * N * 4));
+    hipLaunchKernelGGL((split_planes<false>), dim3(1024), dim3(256), 0, 0, p.W, p.Wh, p.Wl, (long long)p.hW.size() / 8);
+    CK(hipDeviceSynchronize());
+    return p;
+}
+static GemmBatch desc(const Prob& p) {
+    GemmBatch gb; memset(&gb, 0, sizeof(gb));
+    GemmP& g = gb.g[0];
+    g.A = p.A; g.W = p.W; g.bias = p.bias; g.C = p.C; g.R = p.R; g.M = p.M; g.N = p.N; g.K = p.K;
+    g.a_n1 = INT_MAX; g.a_n2 = INT_MAX; g.a_s2 = p.K; g.a_seg = INT_MAX; g.ldw = p.K; g.c_n = INT_MAX; g.c_mod = INT_MAX; g.c_s1 = p.N;
+    g.epi = p.epi; g.alpha = 1.f; g.x_n = 1; g.a_plain = 1; g.c_plain = 1; g.Wh = p.Wh; g.Wl = p.Wl;
+    if (p.ln) { g.ln_g = p.g; g.ln_b = p.b; }
+    return gb;
+}
+template <int MT, int NT>
+static std::vector<float> run(const char* name, Prob& p, int reps) {
+    GemmBatch gb = desc(p);
+    const int ntn = (p.N + 32 * NT - 1) / (32 * NT), ntm = (p.M + 32 * MT - 1) / (32 * MT);
+    dim3 grid(((ntm + 7) / 8) * 8 * ntn, 1, 1);
+    std::vector<float> first((size_t)p.M * p.N), out(first.size());
+    int nondet = 0;
+    for (int r = 0; r < 4; ++r) {
+        CK(hipMemset(p.C, 0xff, first.size() * 4));
+        hipLaunchKernelGGL((gemm_bf<2, false, MT, NT, false>), grid, dim3(256), 0, 0, gb, ntn, ntm);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r ? out.data() : first.data(), p.C, first.size() * 4, hipMemcpyDeviceToHost));
+        if (r && memcmp(out.data(), first.data(), first.size() * 4)) ++nondet;
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_bf<2, false, MT, NT, false>), grid, dim3(256), 0, 0, gb, ntn, ntm);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    printf("  %-10s %8.1f us  %7.1f TFLOP/s (algorithmic)  runs differing from the first: %d/3\n", name, us, 2.0 * p.M * p.N * p.K / us / 1e6, nondet);
+    return first;
+}
+static void reference(const Prob& p, const std::vector<float>& got, const char* name) {
+    double worst = 0;
+    for (int s = 0; s < 24; ++s) {
+        const int m = (int)(((long long)s * 7919 + (s == 23 ? p.M - 1 : 0)) % p.M);
+        std::vector<double> a(p.K);
+        double mu = 0, var = 0;
+        for (int k = 0; k < p.K; ++k) mu += p.hA[(size_t)m * p.K + k];
+        mu /= p.K;
+        for (int k = 0; k < p.K; ++k) { const double d = p.hA[(size_t)m * p.K + k] - mu; var += d * d; }
+        const double rs = 1.0 / sqrt(var / p.K + 1e-5);
+        for (int k = 0; k < p.K; ++k) a[k] = p.ln ? (p.hA[(size_t)m * p.K + k] - mu) * rs * p.hg[k] + p.hbeta[k] : p.hA[(size_t)m * p.K + k];
+        for (int n = 0; n < p.N; n += 7) {
+            double acc = p.hb[n];
+            for (int k = 0; k < p.K; ++k) acc += a[k] * p.hW[(size_t)n * p.K + k];
+            if (p.epi == EPI_SILU) acc = acc / (1.0 + exp(-acc));
+            worst = std::max(worst, fabs(acc - got[(size_t)m * p.N + n]));
+        }
+    }
+    printf("  %-10s max |err| vs double reference on sampled rows: %.3e\n", name, worst);
+}
+static void problem(const char* title, int M, int N, int K, bool ln, int epi) {
+    printf("%s: M=%d N=%d K=%d ln=%d\n", title, M, N, K, (int)ln);
+    Prob p = make(M, N, K, ln, epi);
+    auto r22 = run<2, 2>("<2,2>", p, 20);
+    reference(p, r22, "<2,2>");
+    auto r12 = run<1, 2>("<1,2>", p, 20);
+    auto r42 = run<4, 2>("<4,2>", p, 20);
+    auto r44 = run<4, 4>("<4,4>", p, 20);
+    auto cmp = [&](const char* n, const std::vector<float>& o) {
+        size_t bad = 0, firstbad = 0;
+        for (size_t i = 0; i < o.size(); ++i) if (memcmp(&o[i], &r22[i], 4)) { if (!bad) firstbad = i; ++bad; }
+        printf("  %-10s elements differing from <2,2>: %zu (first at row %zu col %zu)\n", n, bad, firstbad / N, firstbad % N);
+        int shown = 0;
+        for (size_t m = 0; m < (size_t)M && shown < 24; ++m) {
+            int cnt = 0, c0 = -1, c1 = -1; double mx = 0;
+            for (int c = 0; c < N; ++c) if (memcmp(&o[m * N + c], &r22[m * N + c], 4)) { if (c0 < 0) c0 = c; c1 = c; ++cnt; mx = std::max(mx, (double)fabs(o[m * N + c] - r22[m * N + c])); }
+            if (cnt) { printf("      row %zu (tile %zu, row-in-tile %zu): %d cols [%d..%d] max diff %.3e\n", m, m / 128, m % 128, cnt, c0, c1, mx); ++shown; }
+        }
+    };
+    cmp("<1,2>", r12); cmp("<4,2>", r42); cmp("<4,4>", r44);
+    hipFree(p.A); hipFree(p.W); hipFree(p.bias); hipFree(p.C); hipFree(p.R); hipFree(p.g); hipFree(p.b); hipFree(p.Wh); hipFree(p.Wl);
+}
+int main() {
+    problem("ffn1 (LN + SiLU)", 12032, 1024, 256, true, EPI_SILU);
+    if (getenv("GC_ALL")) {
+        problem("ffn2", 12032, 256, 1024, false, EPI_BIAS);
+        problem("qkv-like (LN)", 12032, 256, 256, true, EPI_BIAS);
+        problem("embed-like", 11712, 256, 4864, false, EPI_BIAS);
+    }
+    return 0;
+}
