@@ -35,6 +35,42 @@ __global__ void conv1_relu(const float* __restrict__ x, const float* __restrict_
     }
 }
 
+// conv1_relu_rows: the same convolution with one workgroup per (virtual stream, block of C1_TB output rows) and one thread per
+// channel: the 2*C1_TB+1 input rows sit in LDS (every tap is a broadcast read), the nine weights of the thread's channel in
+// registers, and each output row of 39 x 256 floats leaves as 39 fully coalesced 1 KiB stores.  conv1_relu above spends 18
+// vector loads per 4-byte store (0.9-1.2 TB/s); this one is bound by the 1.1 GB of output it writes.
+#define C1_TB 8
+__global__ __launch_bounds__(256) void conv1_relu_rows(const float* __restrict__ x, const float* __restrict__ w1t /*[9][256]*/,
+                                                       const float* __restrict__ b1, float* __restrict__ y1, int B, int T, int t1,
+                                                       const int* __restrict__ starts, int n_chunks, int b_major) {
+    __shared__ float xs[(2 * C1_TB + 1) * RNNT_IDIM];
+    const int v = blockIdx.x, tb = blockIdx.y * C1_TB;
+    const int cidx = b_major ? v % n_chunks : v / B, b = b_major ? v / n_chunks : v - cidx * B;
+    const int st0 = starts ? starts[cidx] : 0;
+    const int c = threadIdx.x;
+    const int nt = min(C1_TB, t1 - tb), nrows = 2 * nt + 1;
+    const float* xp = x + ((long long)b * T + st0 + 2 * tb) * RNNT_IDIM;
+    for (int e = threadIdx.x; e < nrows * RNNT_IDIM; e += 256) xs[e] = ldg1(xp + e);
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = ldg1(w1t + k * RNNT_D + c);
+    const float bias = ldg1(b1 + c);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const float* r0 = xs + 2 * t * RNNT_IDIM;
+        float* yp = y1 + (((long long)v * t1 + tb + t) * RNNT_F1) * RNNT_D + c;
+#pragma unroll 3
+        for (int f = 0; f < RNNT_F1; ++f) {
+            float acc = bias;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc = fmaf(r0[kh * RNNT_IDIM + 2 * f + kw], w[kh * 3 + kw], acc);
+            stg1_nt(yp + (long long)f * RNNT_D, fmaxf(acc, 0.f));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // layer_norm: y[row] = LN(x[row]) over 256 columns, one wave per row, output row map like gemm C.
 // ------------------------------------------------------------------------------------------------

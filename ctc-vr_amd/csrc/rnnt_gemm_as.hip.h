@@ -1,0 +1,262 @@
+// gemm_as: A-stationary split-operand GEMM for the layer contractions at large M (layer-major encoder, full-context encoder).
+// Part of rnnt_kernels.hip.h (include that umbrella, not this file).
+//
+// The LDS-tiled gemm_bf moves BOTH operands through LDS every 32 k (ds_write_b128 runs at ~79 B/clk/CU: at 64 x 64 tiles the
+// LDS stores alone take as long as the MFMAs) and re-derives the LayerNorm / 16-bit planes of an A tile once per column tile.
+// Here a workgroup owns 16*MT rows and ALL of K = 256: the rows are read, normalised and split ONCE into an LDS operand image
+// (rnnt_fused.hip.h layout, conflict-free ds_read_b128 fragments), and every wave streams its own weight fragments from L2
+// straight into registers in MFMA-fragment order (packed at finalize: one wave instruction = 1 KiB contiguous), 8 KiB per wave
+// in flight ahead of the MFMAs.  No barrier in the main loop, A fragments are read once per k-step for four column tiles
+// (8 ds_read_b128 per 48 MFMAs at MT = 4).  Up to three weight matrices share one staged A (linear_q / k / v).
+// K = 1024 (ffn w_2, N = 256): four K phases re-stage the image, accumulators stay in registers.
+// Products and their order are those of gemm_bf (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi per 32 k, k ascending).
+// Reference contractions: positionwise_feed_forward.py:50-58, attention.py:109-131, convolution.py:138-148.
+#pragma once
+
+#ifdef AS_TRACE   // tools/gemm_check.hip only: per-wave phase time stamps (100 MHz real-time counter)
+__device__ long long as_trace[4096 * 8];
+#define AS_STAMP(k_) { if (lane == 0 && blockIdx.x < 1024) as_trace[(blockIdx.x * 4 + wave) * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); }
+#else
+#define AS_STAMP(k_)
+#endif
+struct AsBatch {
+    GemmP g[3];
+    const uint4* wp[3];     // fragment-major packed weights (pack_frag) of g[i].W
+    int ng;
+};
+
+// Epilogue of one wave's (16*MT) x 64 accumulator block through LDS: straight from the MFMA C layout a lane owns one column of
+// four rows, i.e. 4-byte stores in 64-byte pieces, and the kernel is store-ISSUE bound (measured: 14.5 us of a 28 us launch for
+// 12032 x 256 outputs).  Each wave parks one 16 x 64 row tile at a time in its own 4.25 KiB of LDS and reads it back as
+// float4 per lane (16 lanes = one row's 256 contiguous bytes); bias / activation / residual / GLU are applied on the float4,
+// so every global access of the epilogue is 16 bytes per lane (8 for the halved GLU rows).  Row addressing = c_row_off.
+#define AS_SLD 68
+template <int MT>
+__device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[MT][4], int m0, int n0, float* stage, int lane) {
+    const int i = lane & 15, q = lane >> 4;
+    const int epi = p.epi;
+    const int c4 = (lane & 15) * 4, n = n0 + c4;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = ldg4(p.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(4 * q + r) * AS_SLD + 16 * t + i] = acc[mt][t][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = (lane >> 4) + 4 * j;
+            const int m = m0 + 16 * mt + rr;
+            float4 v = *reinterpret_cast<const float4*>(&stage[rr * AS_SLD + c4]);
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            if (m >= p.M) continue;
+            const long long crow = c_row_off(p, m);
+            if (epi == EPI_GLU) {                                   // (value, gate) interleaved columns -> n / 2
+                stg1(p.C + crow + (n >> 1), v.x * sigmoidf_(v.y));
+                stg1(p.C + crow + (n >> 1) + 1, v.z * sigmoidf_(v.w));
+                continue;
+            }
+            if (epi == EPI_SILU) { v.x *= sigmoidf_(v.x); v.y *= sigmoidf_(v.y); v.z *= sigmoidf_(v.z); v.w *= sigmoidf_(v.w); }
+            else if (epi == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (epi == EPI_SCALE) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
+            else if (epi == EPI_RESID) {
+                const float4 r4 = ldg4(p.R + crow + n);
+                v.x = r4.x + p.alpha * v.x; v.y = r4.y + p.alpha * v.y; v.z = r4.z + p.alpha * v.z; v.w = r4.w + p.alpha * v.w;
+            }
+            stg4(p.C + crow + n, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NUM, int MT>
+__global__ __launch_bounds__(256) void gemm_as(AsBatch P) {
+    using C = FuseCfg<NUM>;
+    constexpr bool F16 = C::F16, LO = C::PLANES == 2;
+    constexpr int U = C::PLANES, R = 16 * MT, ROWB = C::ROWB;     // ROWB = 512: 256 k x 2 bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char as_op[];   // [PLANES][R][512]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int bm0 = blockIdx.x * R;
+    const GemmP& p0 = P.g[0];
+    if (bm0 >= p0.M) return;
+    const int KP = p0.K >> 8;                                     // K phases of 256
+    const unsigned char* rowp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rowp[mt] = as_op + (16 * mt + i) * ROWB;
+    float* estage = reinterpret_cast<float*>(as_op + U * R * ROWB) + wave * (16 * AS_SLD);   // this wave's epilogue staging rows
+
+    // ---- A staging: rows bm0.. of phase kp -> operand image (LayerNorm prologue when set; K = 256 then) -------------------------
+    auto stage = [&](int kp) {
+        if (p0.ln_g) {
+            // 16 lanes per row (4 rows per wave and pass, the passes' reductions independent): two-pass statistics, then the
+            // normalised row goes into the image as 8-float chunks c = l16 + 16 j
+            constexpr int NP = R / 16;                             // passes: rows (wave * 4 + g) + 16 * pass
+            const int g = lane >> 4, l16 = lane & 15;
+            float4 v[NP][4];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const float* rp = p0.A + a_row_off(p0, min(bm0 + wave * 4 + g + 16 * ps, p0.M - 1));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { v[ps][2 * j] = ldg4(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = ldg4(rp + 8 * (l16 + 16 * j) + 4); }
+            }
+            float mu[NP], rs[NP];
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+                mu[ps] = sm * (1.0f / 256.0f);
+            }
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                float qq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dx = v[ps][j].x - mu[ps], dy = v[ps][j].y - mu[ps], dz = v[ps][j].z - mu[ps], dw = v[ps][j].w - mu[ps];
+                    qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
+                rs[ps] = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = l16 + 16 * j;
+                const float4 g0 = ldg4(p0.ln_g + 8 * c), g1 = ldg4(p0.ln_g + 8 * c + 4), b0_ = ldg4(p0.ln_b + 8 * c), b1_ = ldg4(p0.ln_b + 8 * c + 4);
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps) {
+                    const int r = wave * 4 + g + 16 * ps;
+                    const float m_ = mu[ps], s_ = rs[ps];
+                    float4 x0 = v[ps][2 * j], x1 = v[ps][2 * j + 1];
+                    x0.x = (x0.x - m_) * s_ * g0.x + b0_.x; x0.y = (x0.y - m_) * s_ * g0.y + b0_.y; x0.z = (x0.z - m_) * s_ * g0.z + b0_.z; x0.w = (x0.w - m_) * s_ * g0.w + b0_.w;
+                    x1.x = (x1.x - m_) * s_ * g1.x + b1_.x; x1.y = (x1.y - m_) * s_ * g1.y + b1_.y; x1.z = (x1.z - m_) * s_ * g1.z + b1_.z; x1.w = (x1.w - m_) * s_ * g1.w + b1_.w;
+                    uint4 h, l;
+                    split8_16<F16, LO>(x0, x1, h, l);
+                    const int off = op_off<NUM>(r, c);
+                    *reinterpret_cast<uint4*>(as_op + off) = h;
+                    if constexpr (LO) *reinterpret_cast<uint4*>(as_op + R * ROWB + off) = l;
+                }
+            }
+        } else {
+            constexpr int CJ = R * 32 / 256;                       // 8-float chunks per thread
+            float4 va[CJ], vb[CJ];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+                const float* ap = p0.A + a_row_off(p0, min(bm0 + r, p0.M - 1)) + (kp << 8) + 8 * c;
+                va[j] = ldg4(ap);
+                vb[j] = ldg4(ap + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+                uint4 h, l;
+                split8_16<F16, LO>(va[j], vb[j], h, l);
+                const int off = op_off<NUM>(r, c);
+                *reinterpret_cast<uint4*>(as_op + off) = h;
+                if constexpr (LO) *reinterpret_cast<uint4*>(as_op + R * ROWB + off) = l;
+            }
+        }
+    };
+    // ---- weight stream: one unit = one k-step (32 k) of four column tiles = 4 * U vectors per lane ----------------------------------
+    auto bload = [&](uint4 (&b)[4 * U], const uint4* __restrict__ Wp, int KT, int grp, int kt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                typedef unsigned u32x4g_ __attribute__((ext_vector_type(4)));
+                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(Wp + ((long long)((grp * 4 + t) * KT + kt) * U + u) * 64 + lane);
+                b[t * U + u] = make_uint4(v[0], v[1], v[2], v[3]);
+#else
+                b[t * U + u] = Wp[((long long)((grp * 4 + t) * KT + kt) * U + u) * 64 + lane];
+#endif
+            }
+    };
+    auto mma = [&](f32x4_ (&acc)[MT][4], const uint4 (&b)[4 * U], int ks) {
+        uint4 ah[MT], al[LO ? MT : 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int off = ((4 * ks + q) ^ i) << 4;
+            ah[mt] = *reinterpret_cast<const uint4*>(rowp[mt] + off);
+            if constexpr (LO) al[mt] = *reinterpret_cast<const uint4*>(rowp[mt] + R * ROWB + off);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (LO) {
+                    acc[mt][t] = mfma16_<F16>(al[mt], b[t * U], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U + 1], acc[mt][t]);
+                }
+                acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U], acc[mt][t]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4_ acc[MT][4];
+    uint4 b0[4 * U], b1[4 * U];
+    auto zero = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    };
+
+    if (KP > 1) {
+        // ---- one matrix, N = 256: this wave's column group = wave; K phases re-stage the image ------------------------------------
+        const int KT = p0.K >> 5;
+        const uint4* Wp = P.wp[0];
+        zero();
+        bload(b0, Wp, KT, wave, 0);
+        for (int kp = 0; kp < KP; ++kp) {
+            if (kp) __syncthreads();                               // every wave is done with the previous phase's image
+            stage(kp);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 8; ks += 2) {
+                const int kt = kp * 8 + ks;
+                bload(b1, Wp, KT, wave, kt + 1);
+                mma(acc, b0, ks);
+                if (kt + 2 < KT) bload(b0, Wp, KT, wave, kt + 2);
+                mma(acc, b1, ks + 1);
+            }
+        }
+        as_epilogue<MT>(p0, acc, bm0, wave * 64, estage, lane);
+        return;
+    }
+    // ---- K = 256: the image is staged once; (matrix, column group) pairs of this wave one after the other --------------------------
+    AS_STAMP(0)
+    stage(0);
+    AS_STAMP(1)
+    __syncthreads();
+    AS_STAMP(2)
+    int gi = 0, grp = wave;
+    while (gi < P.ng && grp * 64 >= P.g[gi].N) { ++gi; grp = wave; }
+    if (gi < P.ng) bload(b0, P.wp[gi], 8, grp, 0);
+    while (gi < P.ng) {
+        int ngi = gi, ngrp = grp + 4;                              // the pair after this one
+        while (ngi < P.ng && ngrp * 64 >= P.g[ngi].N) { ++ngi; ngrp = wave; }
+        zero();
+        const uint4* Wp = P.wp[gi];
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+            bload(b1, Wp, 8, grp, ks + 1);
+            mma(acc, b0, ks);
+            if (ks + 2 < 8) bload(b0, Wp, 8, grp, ks + 2);
+            else if (ngi < P.ng) bload(b0, P.wp[ngi], 8, ngrp, 0);   // first unit of the next pair: in flight across the epilogue
+            mma(acc, b1, ks + 1);
+        }
+        AS_STAMP(3)
+        as_epilogue<MT>(P.g[gi], acc, bm0, grp * 64, estage, lane);
+        AS_STAMP(4)
+        gi = ngi; grp = ngrp;
+    }
+}

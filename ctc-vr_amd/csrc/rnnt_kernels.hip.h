@@ -10,3 +10,4 @@
 #include "rnnt_beam.hip.h"
 #include "rnnt_misc.hip.h"
 #include "rnnt_fused.hip.h"
+#include "rnnt_gemm_as.hip.h"

@@ -1,6 +1,7 @@
 // Standalone check + timing of the split-operand GEMM variants (gemm_bf<NSPLIT,F16,MT,NT>): bitwise agreement between tile
 // shapes (same K order => identical results), run-to-run reproducibility, a CPU double reference on sampled rows, TFLOP/s.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/gemm_check tools/gemm_check.hip && tools/gemm_check
+#define AS_TRACE 1
 #include "../ctc-vr_amd/csrc/rnnt_kernels.hip.h"
 #include <climits>
 #include <cmath>
@@ -14,6 +15,7 @@ struct Prob {
     int M, N, K; bool ln; int epi;
     float *A, *W, *bias, *C, *R, *g, *b;
     unsigned short *Wh, *Wl;
+    uint4* Wp;
     std::vector<float> hA, hW, hb, hg, hbeta;
 };
 static Prob make(int M, int N, int K, bool ln, int epi) {
@@ -36,6 +38,8 @@ static Prob make(int M, int N, int K, bool ln, int epi) {
     CK(hipMemcpy(p.b, p.hbeta.data(), K * 4, hipMemcpyHostToDevice));
     CK(hipMemset(p.R, 0, (size_t)M * N * 4));
     hipLaunchKernelGGL((split_planes<false>), dim3(1024), dim3(256), 0, 0, p.W, p.Wh, p.Wl, (long long)p.hW.size() / 8);
+    CK(hipMalloc(&p.Wp, p.hW.size() * 4));
+    hipLaunchKernelGGL((pack_frag<RNNT_NUM_BF16X3>), dim3(1024), dim3(256), 0, 0, p.W, N, K, K, p.Wp);
     CK(hipDeviceSynchronize());
     return p;
 }
@@ -72,6 +76,41 @@ static std::vector<float> run(const char* name, Prob& p, int reps) {
     printf("  %-10s %8.1f us  %7.1f TFLOP/s (algorithmic)  runs differing from the first: %d/3\n", name, us, 2.0 * p.M * p.N * p.K / us / 1e6, nondet);
     return first;
 }
+template <int MT>
+static std::vector<float> run_as(const char* name, Prob& p, int reps) {
+    AsBatch ab; memset(&ab, 0, sizeof(ab));
+    ab.g[0] = desc(p).g[0]; ab.wp[0] = p.Wp; ab.ng = 1;
+    const size_t lds = (size_t)16 * MT * 512 * 2 + 4 * 16 * AS_SLD * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_as<RNNT_NUM_BF16X3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((p.M + 16 * MT - 1) / (16 * MT));
+    std::vector<float> first((size_t)p.M * p.N), out(first.size());
+    int nondet = 0;
+    for (int r = 0; r < 4; ++r) {
+        CK(hipMemset(p.C, 0xff, first.size() * 4));
+        hipLaunchKernelGGL((gemm_as<RNNT_NUM_BF16X3, MT>), grid, dim3(256), lds, 0, ab);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r ? out.data() : first.data(), p.C, first.size() * 4, hipMemcpyDeviceToHost));
+        if (r && memcmp(out.data(), first.data(), first.size() * 4)) ++nondet;
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_as<RNNT_NUM_BF16X3, MT>), grid, dim3(256), lds, 0, ab);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps;
+    printf("  %-10s %8.1f us  %7.1f TFLOP/s (algorithmic)  runs differing from the first: %d/3\n", name, us, 2.0 * p.M * p.N * p.K / us / 1e6, nondet);
+    {
+        std::vector<long long> tr(4096 * 8);
+        CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(as_trace), tr.size() * 8));
+        const int nw = std::min<int>(grid.x, 1024) * 4;
+        double ph[4] = {0, 0, 0, 0}; long long t0 = LLONG_MAX, t1 = 0;
+        for (int w = 0; w < nw; ++w) { for (int k = 0; k < 4; ++k) ph[k] += (tr[w * 8 + k + 1] - tr[w * 8 + k]) / 100.0; t0 = std::min(t0, tr[w * 8]); t1 = std::max(t1, tr[w * 8 + 4]); }
+        printf("             per-wave mean us (last column group): stage %.2f, barrier %.2f, K loop(s)+earlier groups %.2f, last epilogue %.2f; first start -> last end %.2f us\n",
+               ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[3] / nw, (t1 - t0) / 100.0);
+    }
+    return first;
+}
 static void reference(const Prob& p, const std::vector<float>& got, const char* name) {
     double worst = 0;
     for (int s = 0; s < 24; ++s) {
@@ -98,28 +137,35 @@ static void problem(const char* title, int M, int N, int K, bool ln, int epi) {
     auto r22 = run<2, 2>("<2,2>", p, 20);
     reference(p, r22, "<2,2>");
     auto r12 = run<1, 2>("<1,2>", p, 20);
-    auto r42 = run<4, 2>("<4,2>", p, 20);
-    auto r44 = run<4, 4>("<4,4>", p, 20);
+    auto r42 = r22, r44 = r22;
+    if (!ln) { r42 = run<4, 2>("<4,2>", p, 20); r44 = run<4, 4>("<4,4>", p, 20); }
+    const bool as_ok = (K == 256 || (K % 256 == 0 && N == 256)) && N % 64 == 0;
+    std::vector<float> a4 = r22, a3 = r22;
+    if (as_ok) { a4 = run_as<4>("as<4>", p, 20); reference(p, a4, "as<4>"); a3 = run_as<3>("as<3>", p, 20); }
     auto cmp = [&](const char* n, const std::vector<float>& o) {
         size_t bad = 0, firstbad = 0;
         for (size_t i = 0; i < o.size(); ++i) if (memcmp(&o[i], &r22[i], 4)) { if (!bad) firstbad = i; ++bad; }
         printf("  %-10s elements differing from <2,2>: %zu (first at row %zu col %zu)\n", n, bad, firstbad / N, firstbad % N);
         int shown = 0;
-        for (size_t m = 0; m < (size_t)M && shown < 24; ++m) {
+        for (size_t m = 0; m < (size_t)M && shown < 6; ++m) {
             int cnt = 0, c0 = -1, c1 = -1; double mx = 0;
             for (int c = 0; c < N; ++c) if (memcmp(&o[m * N + c], &r22[m * N + c], 4)) { if (c0 < 0) c0 = c; c1 = c; ++cnt; mx = std::max(mx, (double)fabs(o[m * N + c] - r22[m * N + c])); }
             if (cnt) { printf("      row %zu (tile %zu, row-in-tile %zu): %d cols [%d..%d] max diff %.3e\n", m, m / 128, m % 128, cnt, c0, c1, mx); ++shown; }
         }
     };
     cmp("<1,2>", r12); cmp("<4,2>", r42); cmp("<4,4>", r44);
-    hipFree(p.A); hipFree(p.W); hipFree(p.bias); hipFree(p.C); hipFree(p.R); hipFree(p.g); hipFree(p.b); hipFree(p.Wh); hipFree(p.Wl);
+    if (as_ok) {
+        cmp("as<4>", a4); cmp("as<3>", a3);
+        double mx = 0; for (size_t e = 0; e < a4.size(); ++e) mx = std::max(mx, (double)fabs(a4[e] - r22[e]));
+        printf("  as<4> max |diff| vs <2,2>: %.3e\n", mx);
+    }
+    hipFree(p.A); hipFree(p.W); hipFree(p.bias); hipFree(p.C); hipFree(p.R); hipFree(p.g); hipFree(p.b); hipFree(p.Wh); hipFree(p.Wl); hipFree(p.Wp);
 }
 int main() {
     problem("ffn1 (LN + SiLU)", 12032, 1024, 256, true, EPI_SILU);
-    if (getenv("GC_ALL")) {
-        problem("ffn2", 12032, 256, 1024, false, EPI_BIAS);
-        problem("qkv-like (LN)", 12032, 256, 256, true, EPI_BIAS);
-        problem("embed-like", 11712, 256, 4864, false, EPI_BIAS);
-    }
+    problem("ffn2", 12032, 256, 1024, false, EPI_BIAS);
+    problem("qkv-like (LN)", 12032, 256, 256, true, EPI_BIAS);
+    problem("out-like", 12032, 256, 256, false, EPI_BIAS);
+    if (getenv("GC_ALL")) problem("embed-like", 11712, 256, 4864, false, EPI_BIAS);
     return 0;
 }
