@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 # launch-site tags of rnnt_profile_begin (include/rnnt_hip.h)
 TAGS = {"conv1": 1, "conv2": 2, "embed": 3, "ffn1": 4, "ffn2": 5, "qkv": 6, "attn": 7, "attn_out": 8, "pw1": 9,
-        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31}
+        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32}
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak of the operand type
 MFMA_PER_ALG = {"fp32": 1, "bf16x3": 3, "f16x3": 3, "bf16": 1}                      # MFMA products issued per algorithmic product
 PEAK_HBM_GBS = 8000.0
@@ -50,7 +50,11 @@ def site_kernel(site, mode):
     gk = "gemm_bf" if bf else "gemm_ns"
     lm = os.environ.get("RNNT_LM", "1") != "0"          # layer-major schedule: one launch per layer over all B*F rows
     if lm:
-        return {"conv1": "conv1_relu", "conv2": f"{gk} (conv2 implicit GEMM, all equal-length chunks in one launch)", "embed": f"{gk} (embed Linear)",
+        if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "qkv", "pw1"):
+            return {"ffn": "ffn_as (LayerNorm + w_1 + SiLU + w_2 + half-step residual [+ norm_final], hidden activation in LDS, M = B*F)",
+                    "qkv": "gemm_as x3 (LayerNorm once, linear_q/k/v from one staged operand image, K/V rows into the cache)",
+                    "pw1": "gemm_as (LayerNorm + pointwise_conv1 + GLU)"}[site]
+        return {"conv1": "conv1_relu_rows", "conv2": f"{gk} (conv2 implicit GEMM, all equal-length chunks in one launch)", "embed": f"{gk} (embed Linear)",
                 "ffn1": f"{gk} (ffn w_1 + LayerNorm prologue + SiLU, M = B*F)", "ffn2": f"{gk} (ffn w_2 + half-step residual, M = B*F)",
                 "qkv": f"{gk} x3 (linear_q/k/v + LayerNorm prologue, K/V rows into the cache)", "attn_out": f"{gk} (linear_out + residual)",
                 "pw1": f"{gk} (pointwise_conv1 + LayerNorm prologue + GLU)", "pw2": f"{gk} (pointwise_conv2 + residual)",
@@ -80,6 +84,7 @@ def site_flops_bytes(site, B, plan):
             t2 = kv if i > 0 else 0
         per = {"ffn1": (2.0 * M * 256 * 1024, 4.0 * (M * 256 + 256 * 1024 + M * 1024), 24),
                "ffn2": (2.0 * M * 256 * 1024, 4.0 * (M * 1024 + 256 * 1024 + 2 * M * 256), 24),
+               "ffn": (4.0 * M * 256 * 1024, 4.0 * (2 * M * 256 + 2 * 256 * 1024), 24),      # fused module: x in, x out, both weight matrices
                "qkv": (2.0 * M * 256 * 768, 4.0 * (M * 256 + 3 * 256 * 256 + 3 * M * 256), 12),
                "attn": (att_fl, 4.0 * (2 * B * kv_rows * 256 + 2 * M * 256 + (kv_rows + len(plan)) * 256), 12),
                "attn_out": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
@@ -279,7 +284,7 @@ def main():
         return sb.decode_script(x, args.chunk, pipelined=True)
 
     # ---- site survey (untimed): one step per launch site -> which kernel dominates -------------------------------------------
-    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
+    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
     survey = {}
     for _ in range(args.warmup):
         toks = step()

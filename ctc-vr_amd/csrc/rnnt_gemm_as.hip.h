@@ -260,3 +260,268 @@ __global__ __launch_bounds__(256) void gemm_as(AsBatch P) {
         gi = ngi; grp = ngrp;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// ffn_as: one PositionwiseFeedForward module with its pre-norm and half-step residual (encoder_layer.py:216-223,250-255;
+// positionwise_feed_forward.py:50-58), optionally followed by the block's final LayerNorm (:257-258), as ONE kernel:
+//     Y = LN_out?( X + alpha * (W2 silu(W1 LN(X) + b1) + b2) )
+// A workgroup owns 16*MT rows.  The [rows x 1024] hidden activation never leaves the CU (unfused it is 49 MB written and read
+// back per FFN at M = 12032: ~20 us of HBM time against ~15 us of MFMA time): the hidden columns are produced 256 at a time
+// into a second LDS operand image and consumed at once as a K = 256 slice of the w_2 contraction, whose accumulators stay in
+// registers.  Weights stream from L2 in fragment order as in gemm_as (2 MB per workgroup: the kernel is bound by the per-CU
+// L2 fetch rate, ~50 GB/s).  Same products and k order as the unfused gemm_bf launches.
+// ------------------------------------------------------------------------------------------------
+struct FfnP {
+    const float* X;
+    float* Y;                         // may alias X
+    const float *ln_g, *ln_b;         // norm_ff / norm_ff_macaron
+    const uint4 *w1p, *w2p;           // packed fragments of w_1 [1024][256] and w_2 [256][1024]
+    const float *b1, *b2;
+    const float *lno_g, *lno_b;       // norm_final (null: off)
+    float alpha;
+    int M;
+};
+#define FFN_FLD 260
+#ifndef FFN_KU
+#define FFN_KU 2
+#endif
+template <int NUM, int MT>
+__global__ __launch_bounds__(256) void ffn_as(FfnP P) {
+    using C = FuseCfg<NUM>;
+    constexpr bool F16 = C::F16, LO = C::PLANES == 2;
+    constexpr int U = C::PLANES, R = 16 * MT, ROWB = C::ROWB, IMG = U * R * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];   // [Xop | Hop | per-wave staging]; the result rows overlay Xop/Hop
+    unsigned char* Xop = ffn_smem;
+    unsigned char* Hop = ffn_smem + IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int bm0 = blockIdx.x * R;
+    if (bm0 >= P.M) return;
+    float* estage = reinterpret_cast<float*>(ffn_smem + 2 * IMG) + wave * (16 * AS_SLD);
+    float* fin = reinterpret_cast<float*>(ffn_smem);                            // [R][FFN_FLD] after the last contraction
+    static_assert(R * FFN_FLD * 4 <= 2 * IMG + 4 * 16 * AS_SLD * 4, "result rows must fit the operand images + staging rows");
+    // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
+    {
+        constexpr int NP = R / 16;
+        const int g = lane >> 4, l16 = lane & 15;
+        float4 v[NP][4];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const float* rp = P.X + (long long)min(bm0 + wave * 4 + g + 16 * ps, P.M - 1) * RNNT_D;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { v[ps][2 * j] = ldg4(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = ldg4(rp + 8 * (l16 + 16 * j) + 4); }
+        }
+        float mu[NP], rs[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+            mu[ps] = sm * (1.0f / 256.0f);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = v[ps][j].x - mu[ps], dy = v[ps][j].y - mu[ps], dz = v[ps][j].z - mu[ps], dw = v[ps][j].w - mu[ps];
+                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
+            rs[ps] = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = l16 + 16 * j;
+            const float4 g0 = ldg4(P.ln_g + 8 * c), g1 = ldg4(P.ln_g + 8 * c + 4), b0_ = ldg4(P.ln_b + 8 * c), b1_ = ldg4(P.ln_b + 8 * c + 4);
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int r = wave * 4 + g + 16 * ps;
+                const float m_ = mu[ps], s_ = rs[ps];
+                float4 x0 = v[ps][2 * j], x1 = v[ps][2 * j + 1];
+                x0.x = (x0.x - m_) * s_ * g0.x + b0_.x; x0.y = (x0.y - m_) * s_ * g0.y + b0_.y; x0.z = (x0.z - m_) * s_ * g0.z + b0_.z; x0.w = (x0.w - m_) * s_ * g0.w + b0_.w;
+                x1.x = (x1.x - m_) * s_ * g1.x + b1_.x; x1.y = (x1.y - m_) * s_ * g1.y + b1_.y; x1.z = (x1.z - m_) * s_ * g1.z + b1_.z; x1.w = (x1.w - m_) * s_ * g1.w + b1_.w;
+                uint4 h, l;
+                split8_16<F16, LO>(x0, x1, h, l);
+                const int off = op_off<NUM>(r, c);
+                *reinterpret_cast<uint4*>(Xop + off) = h;
+                if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
+            }
+        }
+    }
+    auto bload = [&](uint4 (&b)[4 * U], const uint4* __restrict__ Wp, int KT, int grp, int kt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                typedef unsigned u32x4g_ __attribute__((ext_vector_type(4)));
+                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(Wp + ((long long)((grp * 4 + t) * KT + kt) * U + u) * 64 + lane);
+                b[t * U + u] = make_uint4(v[0], v[1], v[2], v[3]);
+#else
+                b[t * U + u] = Wp[((long long)((grp * 4 + t) * KT + kt) * U + u) * 64 + lane];
+#endif
+            }
+    };
+    auto mma = [&](f32x4_ (&acc)[MT][4], const uint4 (&b)[4 * U], int ks, const unsigned char* op) {
+        uint4 ah[MT], al[LO ? MT : 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned char* rp = op + (16 * mt + i) * ROWB + (((4 * ks + q) ^ i) << 4);
+            ah[mt] = *reinterpret_cast<const uint4*>(rp);
+            if constexpr (LO) al[mt] = *reinterpret_cast<const uint4*>(rp + R * ROWB);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (LO) {
+                    acc[mt][t] = mfma16_<F16>(al[mt], b[t * U], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U + 1], acc[mt][t]);
+                }
+                acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U], acc[mt][t]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4_ yacc[MT][4], hacc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    // Weight stream: per 256 hidden columns c, 8 k-steps of w_1's column group 4c + wave, then 8 k-steps of w_2's K slice c for
+    // this wave's 64 output columns.  A pipeline unit = FFN_KU k-steps (8 KiB per wave each); one unit is consumed while the
+    // next is in flight, across the hidden-slice epilogue and the barriers.  The kernel runs at the per-CU L2 fetch rate, which
+    // is set by the bytes in flight.
+    constexpr int KU = FFN_KU;
+    uint4 b0[KU][4 * U], b1[KU][4 * U];
+    auto uload = [&](uint4 (&b)[KU][4 * U], int phase /*2c: w_1, 2c+1: w_2*/, int ks0) {
+        const int c = phase >> 1;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            if (phase & 1) bload(b[k], P.w2p, 32, wave, c * 8 + ks0 + k);
+            else bload(b[k], P.w1p, 8, c * 4 + wave, ks0 + k);
+        }
+    };
+    auto umma = [&](f32x4_ (&acc)[MT][4], const uint4 (&b)[KU][4 * U], int ks0, const unsigned char* op) {
+#pragma unroll
+        for (int k = 0; k < KU; ++k) mma(acc, b[k], ks0 + k, op);
+    };
+    uload(b0, 0, 0);
+    __syncthreads();                                                // Xop complete
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2 * KU) {
+            uload(b1, 2 * c, ks + KU);
+            umma(hacc, b0, ks, Xop);
+            if (ks + 2 * KU < 8) uload(b0, 2 * c, ks + 2 * KU);
+            else uload(b0, 2 * c + 1, 0);
+            umma(hacc, b1, ks + KU, Xop);
+        }
+        {
+            // hidden columns c*256 + wave*64 .. +64 = silu(acc + b1) -> Hop (through the wave's staging rows: 8-float chunks)
+            const int rr0 = lane >> 3, c8 = lane & 7;
+            const float* bp = P.b1 + c * 256 + wave * 64 + 8 * c8;
+            const float4 ba = ldg4(bp), bq = ldg4(bp + 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) estage[(4 * q + r) * AS_SLD + 16 * t + i] = hacc[mt][t][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int rr = rr0 + 8 * ps;
+                    float4 x0 = *reinterpret_cast<const float4*>(&estage[rr * AS_SLD + 8 * c8]);
+                    float4 x1 = *reinterpret_cast<const float4*>(&estage[rr * AS_SLD + 8 * c8 + 4]);
+                    x0.x += ba.x; x0.y += ba.y; x0.z += ba.z; x0.w += ba.w; x1.x += bq.x; x1.y += bq.y; x1.z += bq.z; x1.w += bq.w;
+                    x0.x *= sigmoidf_(x0.x); x0.y *= sigmoidf_(x0.y); x0.z *= sigmoidf_(x0.z); x0.w *= sigmoidf_(x0.w);
+                    x1.x *= sigmoidf_(x1.x); x1.y *= sigmoidf_(x1.y); x1.z *= sigmoidf_(x1.z); x1.w *= sigmoidf_(x1.w);
+                    uint4 h, l;
+                    split8_16<F16, LO>(x0, x1, h, l);
+                    const int off = op_off<NUM>(16 * mt + rr, wave * 8 + c8);
+                    *reinterpret_cast<uint4*>(Hop + off) = h;
+                    if constexpr (LO) *reinterpret_cast<uint4*>(Hop + R * ROWB + off) = l;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();                                            // Hop complete
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2 * KU) {
+            uload(b1, 2 * c + 1, ks + KU);
+            umma(yacc, b0, ks, Hop);
+            if (ks + 2 * KU < 8) uload(b0, 2 * c + 1, ks + 2 * KU);
+            else if (c < 3) uload(b0, 2 * c + 2, 0);
+            umma(yacc, b1, ks + KU, Hop);
+        }
+        __syncthreads();                                            // every wave is done with Hop (after the last slice: with Xop too)
+    }
+    // ---- result rows through LDS: residual, optional norm_final, float4 stores -------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fin[(16 * mt + 4 * q + r) * FFN_FLD + wave * 64 + 16 * t + i] = yacc[mt][t][r];
+    __syncthreads();
+    {
+        const int l16 = tid & 15;
+        float4 b2v[4], gv[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b2v[j] = ldg4(P.b2 + 4 * (l16 + 16 * j));
+            if (P.lno_g) { gv[j] = ldg4(P.lno_g + 4 * (l16 + 16 * j)); bv[j] = ldg4(P.lno_b + 4 * (l16 + 16 * j)); }
+        }
+#pragma unroll
+        for (int ps = 0; ps < MT; ++ps) {
+            const int row = (tid >> 4) + 16 * ps, m = bm0 + row;
+            const long long go = (long long)min(m, P.M - 1) * RNNT_D;
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * (l16 + 16 * j);
+                const float4 y = *reinterpret_cast<const float4*>(&fin[row * FFN_FLD + col]);
+                const float4 x = ldg4(P.X + go + col);
+                v[j] = make_float4(x.x + P.alpha * (y.x + b2v[j].x), x.y + P.alpha * (y.y + b2v[j].y), x.z + P.alpha * (y.z + b2v[j].z), x.w + P.alpha * (y.w + b2v[j].w));
+            }
+            if (P.lno_g) {
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+                const float mu = sm * (1.0f / 256.0f);
+                float qq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+                    qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
+                const float rstd = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j].x = v[j].x * rstd * gv[j].x + bv[j].x; v[j].y = v[j].y * rstd * gv[j].y + bv[j].y;
+                    v[j].z = v[j].z * rstd * gv[j].z + bv[j].z; v[j].w = v[j].w * rstd * gv[j].w + bv[j].w;
+                }
+            }
+            if (m < P.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) stg4(P.Y + go + 4 * (l16 + 16 * j), v[j]);
+            }
+        }
+    }
+}

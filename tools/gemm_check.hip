@@ -161,7 +161,78 @@ static void problem(const char* title, int M, int N, int K, bool ln, int epi) {
     }
     hipFree(p.A); hipFree(p.W); hipFree(p.bias); hipFree(p.C); hipFree(p.R); hipFree(p.g); hipFree(p.b); hipFree(p.Wh); hipFree(p.Wl); hipFree(p.Wp);
 }
+static void problem_ffn(int M, bool lno) {
+    printf("fused FFN: M=%d norm_final=%d\n", M, (int)lno);
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> hX((size_t)M * 256), hW1(1024 * 256), hW2(256 * 1024), hb1(1024), hb2(256), hg(256), hb(256), hgo(256), hbo(256);
+    for (auto& v : hX) v = nd(rng);
+    for (auto& v : hW1) v = nd(rng) * 0.06f;
+    for (auto& v : hW2) v = nd(rng) * 0.03f;
+    for (auto& v : hb1) v = nd(rng) * 0.1f;
+    for (auto& v : hb2) v = nd(rng) * 0.1f;
+    for (int k = 0; k < 256; ++k) { hg[k] = 1.f + 0.1f * nd(rng); hb[k] = 0.1f * nd(rng); hgo[k] = 1.f + 0.1f * nd(rng); hbo[k] = 0.1f * nd(rng); }
+    float *X, *Y, *W1, *W2, *b1, *b2, *g, *b, *go, *bo; uint4 *w1p, *w2p;
+    CK(hipMalloc(&X, hX.size() * 4)); CK(hipMalloc(&Y, hX.size() * 4)); CK(hipMalloc(&W1, hW1.size() * 4)); CK(hipMalloc(&W2, hW2.size() * 4));
+    CK(hipMalloc(&b1, 4096)); CK(hipMalloc(&b2, 1024)); CK(hipMalloc(&g, 1024)); CK(hipMalloc(&b, 1024)); CK(hipMalloc(&go, 1024)); CK(hipMalloc(&bo, 1024));
+    CK(hipMalloc(&w1p, hW1.size() * 4)); CK(hipMalloc(&w2p, hW2.size() * 4));
+    CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b1, hb1.data(), 4096, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b2, hb2.data(), 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(g, hg.data(), 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(b, hb.data(), 1024, hipMemcpyHostToDevice));
+    CK(hipMemcpy(go, hgo.data(), 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(bo, hbo.data(), 1024, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((pack_frag<RNNT_NUM_BF16X3>), dim3(1024), dim3(256), 0, 0, W1, 1024, 256, 256, w1p);
+    hipLaunchKernelGGL((pack_frag<RNNT_NUM_BF16X3>), dim3(1024), dim3(256), 0, 0, W2, 256, 1024, 1024, w2p);
+    CK(hipDeviceSynchronize());
+    FfnP P{X, Y, g, b, w1p, w2p, b1, b2, lno ? go : nullptr, lno ? bo : nullptr, 0.5f, M};
+    constexpr int MT = 3;
+    const size_t lds = (size_t)2 * 2 * 16 * MT * 512 + 4 * 16 * AS_SLD * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_as<RNNT_NUM_BF16X3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((M + 16 * MT - 1) / (16 * MT));
+    std::vector<float> first(hX.size()), out(hX.size());
+    int nondet = 0;
+    for (int r = 0; r < 3; ++r) {
+        hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT>), grid, dim3(256), lds, 0, P);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r ? out.data() : first.data(), Y, hX.size() * 4, hipMemcpyDeviceToHost));
+        if (r && memcmp(out.data(), first.data(), hX.size() * 4)) ++nondet;
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT>), grid, dim3(256), lds, 0, P);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / 20;
+    double worst = 0;
+    for (int s = 0; s < 16; ++s) {
+        const int m = (int)(((long long)s * 7919 + (s == 15 ? M - 1 : 0)) % M);
+        std::vector<double> a(256), h(1024), y(256);
+        double mu = 0, var = 0;
+        for (int k = 0; k < 256; ++k) mu += hX[(size_t)m * 256 + k];
+        mu /= 256;
+        for (int k = 0; k < 256; ++k) { const double d = hX[(size_t)m * 256 + k] - mu; var += d * d; }
+        const double rs = 1.0 / sqrt(var / 256 + 1e-5);
+        for (int k = 0; k < 256; ++k) a[k] = (hX[(size_t)m * 256 + k] - mu) * rs * hg[k] + hb[k];
+        for (int n = 0; n < 1024; ++n) { double acc = hb1[n]; for (int k = 0; k < 256; ++k) acc += a[k] * hW1[(size_t)n * 256 + k]; h[n] = acc / (1.0 + exp(-acc)); }
+        for (int n = 0; n < 256; ++n) { double acc = hb2[n]; for (int k = 0; k < 1024; ++k) acc += h[k] * hW2[(size_t)n * 1024 + k]; y[n] = hX[(size_t)m * 256 + n] + 0.5 * acc; }
+        if (lno) {
+            double m2 = 0, v2 = 0;
+            for (int n = 0; n < 256; ++n) m2 += y[n];
+            m2 /= 256;
+            for (int n = 0; n < 256; ++n) v2 += (y[n] - m2) * (y[n] - m2);
+            const double r2 = 1.0 / sqrt(v2 / 256 + 1e-5);
+            for (int n = 0; n < 256; ++n) y[n] = (y[n] - m2) * r2 * hgo[n] + hbo[n];
+        }
+        for (int n = 0; n < 256; ++n) worst = std::max(worst, fabs(y[n] - first[(size_t)m * 256 + n]));
+    }
+    printf("  ffn_as<3>  %8.1f us  %7.1f TFLOP/s (algorithmic, both contractions)  max |err| vs double reference %.3e  runs differing: %d/2\n",
+           us, 4.0 * M * 256 * 1024 / us / 1e6, worst, nondet);
+}
 int main() {
+    problem_ffn(12032, false);
+    problem_ffn(12032, true);
+    problem_ffn(1000, true);
+    if (getenv("GC_FFN_ONLY")) return 0;
     problem("ffn1 (LN + SiLU)", 12032, 1024, 256, true, EPI_SILU);
     problem("ffn2", 12032, 256, 1024, false, EPI_BIAS);
     problem("qkv-like (LN)", 12032, 256, 256, true, EPI_BIAS);
