@@ -215,3 +215,197 @@ __global__ void dwconv_lm(DwLmP P) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// rel_attention_lm_mfma: the same attention with the three contractions on the exact-f32 matrix instruction
+// (v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain, 2x the scalar FMA rate, and -- what matters here -- operands read from
+// LDS once per 16 x 16 output tile instead of once per output).  rel_attention_lm is bound by its LDS reads (every lane
+// re-reads the query rows for every key: 185 us per layer at 64 x 10 s); this form is bound by the K / V / positional tiles it
+// stages (53 KB per 64 keys and workgroup).
+//   A  scores: S_ac[32 q x 64 keys] = (Q + u) K^T and G[32 q x 80 rows] = (Q + v) P^T for the 80 positional rows the block's
+//      units can address in this key tile, both to LDS; a unit's matrix_bd is G shifted by its window offset
+//      (encoder.py:257: the positional window is rebuilt per chunk; attention.py:406-409: no rel_shift)
+//   B  softmax: lane = key, one wave per 8 query slots, online maximum / sum; probabilities overwrite S_ac
+//   C  O[32 q x 64] = alpha O + P V on the accumulators
+// 4 waves: wave w owns query tile w & 1 (16 slots = 4 units) and half w >> 1 of the key tiles (A) / d tiles (C).
+// grid = (B*H, n_blocks), block = 256, dynamic LDS = LM2_LDS bytes.  Same unit / block tables as rel_attention_lm.
+// ------------------------------------------------------------------------------------------------
+#define LM2_LD 68
+#define LM2_GLD 84
+#define LM2_LDS ((64 * LM2_LD + (64 + LM_PEXT) * LM2_LD + 64 * LM2_LD + 32 * LM2_LD + 32 * LM2_GLD + 64) * 4)
+__global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
+    extern __shared__ __attribute__((aligned(16))) float lm2_smem[];
+    float* Ks = lm2_smem;                               // [64][68]
+    float* Ps = Ks + 64 * LM2_LD;                       // [80][68]
+    float* Vs = Ps + (64 + LM_PEXT) * LM2_LD;           // [64][68]
+    float* Sx = Vs + 64 * LM2_LD;                       // [32][68]  matrix_ac scores, then probabilities
+    float* Gx = Sx + 32 * LM2_LD;                       // [32][84]  (Q + v) P^T over the tile's 80 positional rows
+    float* al = Gx + 32 * LM2_GLD;                      // [32] rescale factor of the tile, then 1 / sum
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int qt = wave & 1, hf = wave >> 1;
+    const LmBlock* __restrict__ blk = P.blocks + blockIdx.y;
+    const int n_units = ldgi(&blk->n_units), amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
+    // softmax role: query slots 8*wave .. +7 = units 2*wave, 2*wave + 1
+    int s_ks[2], s_ke[2], s_prel[2];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+        const int u = 2 * wave + uu;
+        s_ks[uu] = 0; s_ke[uu] = 0; s_prel[uu] = 0;
+        if (u < n_units) {
+            s_ks[uu] = ldgi(&blk->u[u].kv_start); s_ke[uu] = s_ks[uu] + ldgi(&blk->u[u].T2);
+            s_prel[uu] = ldgi(&blk->u[u].pshift) - pmin;
+        }
+    }
+    // contraction role: this lane's query row 16*qt + i = (unit 4*qt + i/4, slot i % 4)
+    const int my_u = 4 * qt + (i >> 2), my_iq = i & 3;
+    int my_f = -1;
+    if (my_u < n_units && my_iq < ldgi(&blk->u[my_u].nq)) my_f = ldgi(&blk->u[my_u].f0) + my_iq;
+    float4 qu[4], qv[4];
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+        const int d = 16 * sp + 4 * kq;
+        float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (my_f >= 0) qq = ldg4(P.q + ((long long)b * P.F + my_f) * RNNT_D + h * RNNT_DK + d);
+        const float4 bu = ldg4(P.bias_u + h * RNNT_DK + d), bv = ldg4(P.bias_v + h * RNNT_DK + d);
+        qu[sp] = make_float4(qq.x + bu.x, qq.y + bu.y, qq.z + bu.z, qq.w + bu.w);
+        qv[sp] = make_float4(qq.x + bv.x, qq.y + bv.y, qq.z + bv.z, qq.w + bv.w);
+    }
+    f32x4m o[2];
+    o[0] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+    o[1] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+    float mrun[8], lrun[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+    const float* kbase = P.kc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
+    const float* vbase = P.vc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
+    const float* pbase = P.ptab + h * RNNT_DK;
+    for (int a0 = amin; a0 < amax; a0 += 64) {
+        __syncthreads();                                            // the previous tile's PV is done with Vs / Sx / al
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c4 = e & 15;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (a0 + r < amax) {
+                kv = ldg4(kbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
+                vv = ldg4(vbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(&Ks[r * LM2_LD + c4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[r * LM2_LD + c4 * 4]) = vv;
+        }
+        for (int e = tid; e < (64 + LM_PEXT) * 16; e += 256) {
+            const int r = e >> 4, c4 = e & 15;
+            const int pr = a0 + pmin + r;
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr >= 0 && pr < RNNT_PE_LEN) pv = ldg4(pbase + (long long)pr * RNNT_D + c4 * 4);
+            *reinterpret_cast<float4*>(&Ps[r * LM2_LD + c4 * 4]) = pv;
+        }
+        __syncthreads();
+        // ---- A: matrix_ac tiles and G tiles of this wave's query tile ------------------------------------------------------------
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kt = 2 * hf + kk;
+            f32x4m acc = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                const float4 kf = *reinterpret_cast<const float4*>(&Ks[(16 * kt + i) * LM2_LD + 16 * sp + 4 * kq]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[sp].x, kf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[sp].y, kf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[sp].z, kf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[sp].w, kf.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Sx[(16 * qt + 4 * kq + r) * LM2_LD + 16 * kt + i] = acc[r];
+        }
+        for (int gt = (hf ? 3 : 0); gt < (hf ? 5 : 3); ++gt) {
+            f32x4m acc = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                const float4 pf = *reinterpret_cast<const float4*>(&Ps[(16 * gt + i) * LM2_LD + 16 * sp + 4 * kq]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[sp].x, pf.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[sp].y, pf.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[sp].z, pf.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[sp].w, pf.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gx[(16 * qt + 4 * kq + r) * LM2_GLD + 16 * gt + i] = acc[r];
+        }
+        __syncthreads();
+        // ---- B: softmax of query slots 8*wave .. +7, lane = key.  The eight rows' reductions advance in lock step (step outer,
+        //      row inner): eight independent cross-lane exchanges per step instead of 96 dependent ones ---------------------------------
+        {
+            float sc[8], mx[8], pe_[8], sm[8];
+            bool live[2];
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) live[uu] = a0 < s_ke[uu] && a0 + 64 > s_ks[uu];   // wave-uniform
+            const int a = a0 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int qs = 8 * wave + j, uu = j >> 2;
+                const bool valid = live[uu] && a >= s_ks[uu] && a < s_ke[uu];
+                sc[j] = valid ? (Sx[qs * LM2_LD + lane] + Gx[qs * LM2_GLD + lane + s_prel[uu]]) * 0.125f : -INFINITY;
+                mx[j] = sc[j];
+            }
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], o_, 64));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float mnew = fmaxf(mrun[j], mx[j]);
+                pe_[j] = sc[j] > -INFINITY ? expf(sc[j] - mnew) : 0.f;
+                sm[j] = pe_[j];
+                mx[j] = live[j >> 2] ? expf(mrun[j] - mnew) : 1.0f;          // alpha (first live tile: exp(-inf) = 0)
+                if (live[j >> 2]) mrun[j] = mnew;
+            }
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm[j] += __shfl_xor(sm[j], o_, 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int qs = 8 * wave + j;
+                lrun[j] = lrun[j] * mx[j] + sm[j];
+                Sx[qs * LM2_LD + lane] = pe_[j];
+                if (lane == 0) al[qs] = mx[j];
+            }
+        }
+        __syncthreads();
+        // ---- C: O = alpha O + P V for d tiles 2*hf, 2*hf + 1 ---------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a_ = al[16 * qt + 4 * kq + r];
+            o[0][r] *= a_;
+            o[1][r] *= a_;
+        }
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const float4 pf = *reinterpret_cast<const float4*>(&Sx[(16 * qt + i) * LM2_LD + 16 * sp + 4 * kq]);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                const float* vp = Vs + (16 * sp + 4 * kq) * LM2_LD + 16 * (2 * hf + dd) + i;
+                o[dd] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, vp[0], o[dd], 0, 0, 0);
+                o[dd] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, vp[LM2_LD], o[dd], 0, 0, 0);
+                o[dd] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, vp[2 * LM2_LD], o[dd], 0, 0, 0);
+                o[dd] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, vp[3 * LM2_LD], o[dd], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (lane == 0) al[8 * wave + j] = lrun[j] > 0.f ? 1.0f / lrun[j] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * qt + 4 * kq + r;                       // query slot of accumulator row r
+        const int u = row >> 2, iq = row & 3;
+        if (u < n_units && iq < ldgi(&blk->u[u].nq)) {
+            const long long m = (long long)b * P.F + ldgi(&blk->u[u].f0) + iq;
+            const float li = al[row];
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) stg1(P.out + m * RNNT_D + h * RNNT_DK + 16 * (2 * hf + dd) + i, o[dd][r] * li);
+        }
+    }
+}
