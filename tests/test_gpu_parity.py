@@ -601,3 +601,87 @@ def test_prefix_beam_search_matches_reference(seed, np_state_dict, numerics):
     assert [b[0] for b in beam] == want
     assert max(abs(b[1] - s) for b, s in zip(beam, g["scores"])) < 2e-3
     assert maxdiff(m._prefix_states[0].cpu().numpy()[None], g["h"]) < LOGIT_TOL
+
+
+def test_full_size_beam_properties(np_state_dict):
+    """BASELINE configs[2] at full size (64 streams x 1000 frames, chunk 16, beam 4), size-independent properties: the
+    whole-utterance form (one encoder call + one rnnt_beam_advance) equals the per-chunk beam API (hypotheses and scores), a
+    stream's beam does not depend on its batch position, and two streams equal the CPU oracle's beam search run chunk by chunk
+    (online_rnnt_model.py:389-522 restated in oracle/rnnt_oracle.py, pinned by the reference's beam goldens)."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    sd_np = np_state_dict(0)
+    B = 64
+    x_cpu = torch.from_numpy(T.synth_fbank(B, 1000, seed=1234))
+    x = x_cpu.cuda().contiguous()
+    sb = StreamingBatch(sd_np, B, max_chunk_frames=24, max_cache_frames=200, max_enc_frames=200, max_tokens=64, max_beam=4)
+    sig = lambda beams: [[(tuple(h.tokens), round(h.log_prob, 3)) for h in bm] for bm in beams]
+    whole = sb.beam_script(x, 16, 4, pipelined=True)
+    assert sig(sb.beam_script(x, 16, 4, pipelined=True)) == sig(whole)                    # deterministic
+    per_chunk = sb.beam_script(x, 16, 4, pipelined=False)
+    for b in range(B):
+        assert [h.tokens for h in per_chunk[b]] == [h.tokens for h in whole[b]], b
+        assert max(abs(p.log_prob - q.log_prob) for p, q in zip(per_chunk[b], whole[b])) < 2e-3, b
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(11))
+    permuted = sb.beam_script(x[perm.cuda()].contiguous(), 16, 4, pipelined=True)
+    for i in range(B):
+        assert sig([permuted[i]]) == sig([whole[int(perm[i])]]), i                           # no cross-stream leakage
+    sd = O.to_torch_sd(sd_np)
+    for b in (0, 37):
+        st = O.OracleStream(sd, T.BLANK, 16)
+        for (a, e) in T.chunk_plan(1000, 16):
+            ob = st.process_single_chunk_beam_search(x_cpu[b:b + 1, a:e], beam_size=4)
+        assert [h.tokens for h in whole[b]] == [h.tokens for h in ob], b
+        assert max(abs(p.log_prob - q.log_prob) for p, q in zip(whole[b], ob)) < 2e-3, b
+    assert len(whole[0][0].tokens) > 0
+
+
+def test_full_context_long_utterance(np_state_dict, numerics):
+    """BASELINE configs[4] shape: a 3000-frame utterance (749 encoder frames: 12 key tiles of the full-context attention; the
+    reference golden covers 74 frames) against the CPU oracle's full-context encoder (encoder.py:121-180 with
+    decoding_chunk_size = -1), and position invariance inside a batch of 32 x 30 s: the same utterance in slots 0, 5 and 31
+    between different neighbours gives the same frames."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.lib import RnntEngine
+    sd_np = np_state_dict(0)
+    Bf, Tn, tq = 32, 3000, 749
+    eng = RnntEngine(max_streams=Bf, max_chunk_frames=Tn, max_cache_frames=760, max_enc_frames=8, vocab_size=T.VOCAB, blank_id=T.BLANK)
+    eng.load_state_dict(sd_np, numerics=numerics)
+    xs = torch.from_numpy(T.synth_fbank(4, Tn, seed=77))
+    xb = torch.stack([xs[0] if b in (0, 5, 31) else xs[1 + b % 3] for b in range(Bf)]).cuda().contiguous()
+    out = torch.empty(Bf, tq, 256, device="cuda")
+    lens = np.full(Bf, Tn, np.int32)
+    s = torch.cuda.current_stream().cuda_stream
+    assert eng.encoder_full(xb.data_ptr(), lens, Bf, Tn, out.data_ptr(), s) == tq
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert maxdiff(o[5], o[0]) < 1e-5 and maxdiff(o[31], o[0]) < 1e-5
+    want, _ = O.encoder_full(O.to_torch_sd(sd_np), xs[0:1], torch.tensor([Tn]))
+    assert tuple(want.shape) == (1, tq, 256)
+    assert maxdiff(o[0], want[0].numpy()) < LOGIT_TOL
+    one = torch.empty(1, tq, 256, device="cuda")
+    x1 = xs[0:1].cuda().contiguous()
+    assert eng.encoder_full(x1.data_ptr(), lens[:1], 1, Tn, one.data_ptr(), s) == tq
+    torch.cuda.synchronize()
+    assert maxdiff(one.cpu().numpy()[0], o[0]) < 1e-5                                       # B = 1 call == its slot in the batch of 32
+
+
+def test_weight_reload_invalidates_cached_launch_state(np_state_dict, monkeypatch):
+    """A second load_state_dict on a live context (same architecture, other weights) must not replay anything that holds
+    addresses or values of the first blob: the launched decode path (RNNT_PERSISTENT=0) replays hipGraphs whose kernel
+    arguments point into the weight blob, the whole-utterance schedules cache descriptor tables.  Tokens after the reload
+    equal a fresh context's, for both APIs."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    monkeypatch.setenv("RNNT_PERSISTENT", "0")
+    x = torch.from_numpy(T.synth_fbank(3, 400, seed=5)).cuda().contiguous()
+    mk = lambda seed: StreamingBatch(np_state_dict(seed), 3, max_chunk_frames=32, max_cache_frames=128, max_enc_frames=128)
+    fresh = mk(1)
+    want_pc = fresh.decode_script(x, 16, per_chunk_decode=True)
+    want_wu = fresh.decode_script(x, 16, pipelined=True)
+    assert want_pc == want_wu
+    sb = mk(0)
+    first = sb.decode_script(x, 16, per_chunk_decode=True)
+    assert sb.decode_script(x, 16, pipelined=True) == first and first != want_pc
+    sb.engine.load_state_dict(np_state_dict(1))
+    assert sb.decode_script(x, 16, per_chunk_decode=True) == want_pc
+    assert sb.decode_script(x, 16, pipelined=True) == want_wu

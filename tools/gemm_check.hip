@@ -229,14 +229,27 @@ static void problem_ffn(int M, bool lno) {
            us, 4.0 * M * 256 * 1024 / us / 1e6, worst, nondet);
 }
 int main() {
-    problem_ffn(12032, false);
-    problem_ffn(12032, true);
-    problem_ffn(1000, true);
+    if (!getenv("GC_CONV2")) {
+        problem_ffn(12032, false);
+        problem_ffn(12032, true);
+        problem_ffn(1000, true);
+    }
     if (getenv("GC_FFN_ONLY")) return 0;
+    if (getenv("GC_CONV2")) {
+        printf("conv2-like: M=222528 N=256 K=2304\n");
+        Prob p = make(222528, 256, 2304, false, EPI_RELU);
+        auto r22 = run<2, 2>("<2,2>", p, 5);
+        auto r48 = run<4, 8>("<4,8>", p, 5);
+        auto r28 = run<2, 8>("<2,8>", p, 5);
+        auto r44 = run<4, 4>("<4,4>", p, 5);
+        printf("  <4,8> == <2,2>: %d, <2,8> == <2,2>: %d\n", (int)!memcmp(r48.data(), r22.data(), r22.size() * 4), (int)!memcmp(r28.data(), r22.data(), r22.size() * 4));
+        return 0;
+    }
     problem("ffn1 (LN + SiLU)", 12032, 1024, 256, true, EPI_SILU);
     problem("ffn2", 12032, 256, 1024, false, EPI_BIAS);
     problem("qkv-like (LN)", 12032, 256, 256, true, EPI_BIAS);
     problem("out-like", 12032, 256, 256, false, EPI_BIAS);
     if (getenv("GC_ALL")) problem("embed-like", 11712, 256, 4864, false, EPI_BIAS);
+
     return 0;
 }
