@@ -282,26 +282,43 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
     const float* kbase = P.kc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
     const float* vbase = P.vc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
     const float* pbase = P.ptab + h * RNNT_DK;
+    // K / V / positional rows of a tile travel global -> registers -> LDS; the NEXT tile's loads are issued as soon as this tile's
+    // rows are in LDS, so their L2 latency hides behind the three phases (13 float4 per thread in flight)
+    float4 rk[4], rv[4], rp[5];
+    auto tile_load = [&](int a0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, r = e >> 4, c4 = e & 15;
+            rk[j] = make_float4(0.f, 0.f, 0.f, 0.f); rv[j] = rk[j];
+            if (a0 + r < amax) {
+                rk[j] = ldg4(kbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
+                rv[j] = ldg4(vbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int e = tid + 256 * j, r = e >> 4, c4 = e & 15;
+            const int pr = a0 + pmin + r;
+            rp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr >= 0 && pr < RNNT_PE_LEN) rp[j] = ldg4(pbase + (long long)pr * RNNT_D + c4 * 4);
+        }
+    };
+    tile_load(amin);
     for (int a0 = amin; a0 < amax; a0 += 64) {
         __syncthreads();                                            // the previous tile's PV is done with Vs / Sx / al
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int r = e >> 4, c4 = e & 15;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (a0 + r < amax) {
-                kv = ldg4(kbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
-                vv = ldg4(vbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
-            }
-            *reinterpret_cast<float4*>(&Ks[r * LM2_LD + c4 * 4]) = kv;
-            *reinterpret_cast<float4*>(&Vs[r * LM2_LD + c4 * 4]) = vv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, r = e >> 4, c4 = e & 15;
+            *reinterpret_cast<float4*>(&Ks[r * LM2_LD + c4 * 4]) = rk[j];
+            *reinterpret_cast<float4*>(&Vs[r * LM2_LD + c4 * 4]) = rv[j];
         }
-        for (int e = tid; e < (64 + LM_PEXT) * 16; e += 256) {
-            const int r = e >> 4, c4 = e & 15;
-            const int pr = a0 + pmin + r;
-            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pr >= 0 && pr < RNNT_PE_LEN) pv = ldg4(pbase + (long long)pr * RNNT_D + c4 * 4);
-            *reinterpret_cast<float4*>(&Ps[r * LM2_LD + c4 * 4]) = pv;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int e = tid + 256 * j, r = e >> 4, c4 = e & 15;
+            *reinterpret_cast<float4*>(&Ps[r * LM2_LD + c4 * 4]) = rp[j];
         }
         __syncthreads();
+        if (a0 + 64 < amax) tile_load(a0 + 64);
         // ---- A: matrix_ac tiles and G tiles of this wave's query tile ------------------------------------------------------------
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
