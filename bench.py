@@ -58,7 +58,7 @@ def site_kernel(site, mode):
                 "ffn1": f"{gk} (ffn w_1 + LayerNorm prologue + SiLU, M = B*F)", "ffn2": f"{gk} (ffn w_2 + half-step residual, M = B*F)",
                 "qkv": f"{gk} x3 (linear_q/k/v + LayerNorm prologue, K/V rows into the cache)", "attn_out": f"{gk} (linear_out + residual)",
                 "pw1": f"{gk} (pointwise_conv1 + LayerNorm prologue + GLU)", "pw2": f"{gk} (pointwise_conv2 + residual)",
-                "attn": "rel_attention_lm (8 chunks per workgroup)", "dwconv": "dwconv_lm", "enc_proj": "joint.enc_ffn projection (+ after_norm prologue)"}.get(site, site)
+                "attn": "rel_attention_lm_mfma (8 chunks per workgroup, v_mfma_f32_16x16x4_f32)", "dwconv": "dwconv_lm", "enc_proj": "joint.enc_ffn projection (+ after_norm prologue)"}.get(site, site)
     return {"conv1": "conv1_relu", "conv2": "gemm_bf<4,4> (conv2 implicit GEMM)" if bf else "gemm_ns<2,2,32> (conv2 implicit GEMM)",
             "embed": "gemm_bf (embed Linear)" if bf else "gemm_ns / gemm16 (embed Linear)",
             "block_front": "block_front (LN + FFN-macaron + LN + q/k/v, fused)", "block_back": "block_back (out-proj + conv module + FFN + LN, fused)",
@@ -128,7 +128,14 @@ def roof(site, mode, fl, by, ms, n_launches, steps):
     if n_launches <= 0 or ms <= 0:
         return None
     s = ms * 1e-3
-    if site in HBM_SITES:
+    lm = os.environ.get("RNNT_LM", "1") != "0"
+    if site == "attn" and lm:
+        # layer-major attention runs its three contractions on the exact-f32 matrix instruction in every numerics mode
+        ach = fl * steps / s / 1e12
+        r = {"bound": "mfma", "kernel": site_kernel(site, mode), "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["fp32"], 4),
+             "traffic": None, "note": "algorithmic FLOPs (3 queries per chunk); the kernel issues 4/3 of them for the padded 4-slot units plus 25 % for the positional rows the units' windows share",
+             "achieved_GBs_on_layer_major_bytes": round(by * steps / s / 1e9, 1)}
+    elif site in HBM_SITES:
         ach = by * steps / s / 1e9
         r = {"bound": "hbm", "kernel": site_kernel(site, mode), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
     else:
@@ -156,7 +163,8 @@ def pmc_traffic(kernel_prefixes):
 
 
 PMC_PREFIX = {"block_front": ["void block_front"], "block_back": ["void block_back"], "conv2": ["void gemm_bf<2, false, 4, 4", "void gemm_ns<2, 2, 32"],
-              "attn": ["rel_attention_stream_tab"], "ffn2": ["void gemm_ns_tab<1, 1, 64"], "dwconv": ["dwconv_bn_silu_tab"]}
+              "attn": ["rel_attention_lm_mfma", "rel_attention_stream_tab"], "ffn2": ["void gemm_ns_tab<1, 1, 64"], "dwconv": ["dwconv_lm", "dwconv_bn_silu_tab"],
+              "ffn": ["void ffn_as"], "conv1": ["conv1_relu_rows"]}
 
 
 def spawn_ranks(args):
