@@ -19,6 +19,7 @@ __device__ long long as_trace[4096 * 8];
 #else
 #define AS_STAMP(k_)
 #endif
+#define AS_MT_ 3
 struct AsBatch {
     GemmP g[3];
     const uint4* wp[3];     // fragment-major packed weights (pack_frag) of g[i].W
@@ -280,11 +281,19 @@ struct FfnP {
     const float *lno_g, *lno_b;       // norm_final (null: off)
     float alpha;
     int M;
+    // optional tail (FFN-macaron -> self-attention projections): n_tail matrices applied to LN_t(result rows), K = 256, N = 256
+    // each, epilogue / output map from the descriptors (linear_q to a buffer, linear_k / linear_v rows into the cache)
+    int n_tail;
+    const float *lnt_g, *lnt_b;       // norm_mha
+    GemmP tg[3];
+    const uint4* twp[3];
 };
+#define FFN_TIMG 51200                // byte offset of the tail's operand image (behind the result rows)
 #define FFN_FLD 260
 #ifndef FFN_KU
 #define FFN_KU 2
 #endif
+#define FFN_LDS(NUM_) ((size_t)FFN_TIMG + (size_t)FuseCfg<NUM_>::PLANES * 16 * AS_MT_ * FuseCfg<NUM_>::ROWB + 4 * 16 * AS_SLD * 4)
 template <int NUM, int MT>
 __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
     using C = FuseCfg<NUM>;
@@ -522,6 +531,53 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) stg4(P.Y + go + 4 * (l16 + 16 * j), v[j]);
             }
+            if (P.n_tail > 0) {                                     // LN_t(result row) -> the tail's operand image
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+                const float mu = sm * (1.0f / 256.0f);
+                float qq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+                    qq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
+                const float rstd = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 gt = ldg4(P.lnt_g + 4 * (l16 + 16 * j)), bt = ldg4(P.lnt_b + 4 * (l16 + 16 * j));
+                    op_store4<NUM>(ffn_smem + FFN_TIMG, R, row, 4 * (l16 + 16 * j),
+                                   make_float4(v[j].x * rstd * gt.x + bt.x, v[j].y * rstd * gt.y + bt.y, v[j].z * rstd * gt.z + bt.z, v[j].w * rstd * gt.w + bt.w));
+                }
+            }
+        }
+    }
+    if (P.n_tail > 0) {
+        static_assert(R * FFN_FLD * 4 <= FFN_TIMG, "the tail image must start behind the result rows");
+        const unsigned char* Top = ffn_smem + FFN_TIMG;
+        float* estage2 = reinterpret_cast<float*>(ffn_smem + FFN_TIMG + IMG) + wave * (16 * AS_SLD);
+        __syncthreads();                                            // tail image complete
+        bload(b0[0], P.twp[0], 8, wave, 0);
+#pragma unroll 1
+        for (int gi = 0; gi < P.n_tail; ++gi) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+            const uint4* Wp = P.twp[gi];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks += 2) {
+                bload(b0[1], Wp, 8, wave, ks + 1);
+                mma(hacc, b0[0], ks, Top);
+                if (ks + 2 < 8) bload(b0[0], Wp, 8, wave, ks + 2);
+                else if (gi + 1 < P.n_tail) bload(b0[0], P.twp[gi + 1], 8, wave, 0);
+                mma(hacc, b0[1], ks + 1, Top);
+            }
+            as_epilogue<MT>(P.tg[gi], hacc, bm0, wave * 64, estage2, lane);
         }
     }
 }

@@ -184,7 +184,10 @@ static void problem_ffn(int M, bool lno) {
     hipLaunchKernelGGL((pack_frag<RNNT_NUM_BF16X3>), dim3(1024), dim3(256), 0, 0, W2, 256, 1024, 1024, w2p);
     CK(hipDeviceSynchronize());
     FfnP P{X, Y, g, b, w1p, w2p, b1, b2, lno ? go : nullptr, lno ? bo : nullptr, 0.5f, M};
-    constexpr int MT = 3;
+#ifndef FFN_MT
+#define FFN_MT 3
+#endif
+    constexpr int MT = FFN_MT;
     const size_t lds = (size_t)2 * 2 * 16 * MT * 512 + 4 * 16 * AS_SLD * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_as<RNNT_NUM_BF16X3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((M + 16 * MT - 1) / (16 * MT));
@@ -225,8 +228,8 @@ static void problem_ffn(int M, bool lno) {
         }
         for (int n = 0; n < 256; ++n) worst = std::max(worst, fabs(y[n] - first[(size_t)m * 256 + n]));
     }
-    printf("  ffn_as<3>  %8.1f us  %7.1f TFLOP/s (algorithmic, both contractions)  max |err| vs double reference %.3e  runs differing: %d/2\n",
-           us, 4.0 * M * 256 * 1024 / us / 1e6, worst, nondet);
+    printf("  ffn_as<%d>  %8.1f us  %7.1f TFLOP/s (algorithmic, both contractions)  max |err| vs double reference %.3e  runs differing: %d/2\n",
+           MT, us, 4.0 * M * 256 * 1024 / us / 1e6, worst, nondet);
 }
 int main() {
     if (!getenv("GC_CONV2")) {
