@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 # launch-site tags of rnnt_profile_begin (include/rnnt_hip.h)
 TAGS = {"conv1": 1, "conv2": 2, "embed": 3, "ffn1": 4, "ffn2": 5, "qkv": 6, "attn": 7, "attn_out": 8, "pw1": 9,
-        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33}
+        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33, "out_pw1": 34}
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak of the operand type
 MFMA_PER_ALG = {"fp32": 1, "bf16x3": 3, "f16x3": 3, "bf16": 1}                      # MFMA products issued per algorithmic product
 PEAK_HBM_GBS = 8000.0
@@ -50,8 +50,9 @@ def site_kernel(site, mode):
     gk = "gemm_bf" if bf else "gemm_ns"
     lm = os.environ.get("RNNT_LM", "1") != "0"          # layer-major schedule: one launch per layer over all B*F rows
     if lm:
-        if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "ffn_qkv", "qkv", "pw1"):
-            return {"ffn_qkv": "ffn_as + tail (macaron FFN module, then LayerNorm + linear_q/k/v from its result rows in LDS; K/V rows into the cache)",
+        if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "ffn_qkv", "out_pw1", "qkv", "pw1"):
+            return {"out_pw1": "ffn_as chain (linear_out + residual, then LayerNorm + pointwise_conv1 + GLU from the result rows in LDS)",
+                    "ffn_qkv": "ffn_as + tail (macaron FFN module, then LayerNorm + linear_q/k/v from its result rows in LDS; K/V rows into the cache)",
                     "ffn": "ffn_as (LayerNorm + w_1 + SiLU + w_2 + half-step residual [+ norm_final], hidden activation in LDS, M = B*F)",
                     "qkv": "gemm_as x3 (LayerNorm once, linear_q/k/v from one staged operand image, K/V rows into the cache)",
                     "pw1": "gemm_as (LayerNorm + pointwise_conv1 + GLU)"}[site]
@@ -92,6 +93,7 @@ def site_flops_bytes(site, B, plan):
                "attn": (att_fl, 4.0 * (2 * B * kv_rows * 256 + 2 * M * 256 + (kv_rows + len(plan)) * 256), 12),
                "attn_out": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
                "pw1": (2.0 * M * 256 * 512, 4.0 * (M * 256 + 512 * 256 + M * 256), 12),
+               "out_pw1": (2.0 * M * 256 * 768, 4.0 * (4 * M * 256 + 3 * 256 * 256), 12),   # linear_out + residual, norm_conv + pointwise_conv1 + GLU: att in, x in/out, GLU rows out
                "dwconv": (2.0 * M * 256 * 31, 4.0 * (B * (30 + F) * 256 + 2 * M * 256), 12),
                "pw2": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
                "enc_proj": (2.0 * M * 256 * 256, 4.0 * (2 * M * 256 + 256 * 256), 1)}
@@ -295,7 +297,7 @@ def main():
         return sb.decode_script(x, args.chunk, pipelined=True)
 
     # ---- site survey (untimed): one step per launch site -> which kernel dominates -------------------------------------------
-    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn_qkv", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
+    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn_qkv", "out_pw1", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
     survey = {}
     for _ in range(args.warmup):
         toks = step()

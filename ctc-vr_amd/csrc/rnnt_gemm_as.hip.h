@@ -284,7 +284,10 @@ struct FfnP {
     // optional tail (FFN-macaron -> self-attention projections): n_tail matrices applied to LN_t(result rows), K = 256, N = 256
     // each, epilogue / output map from the descriptors (linear_q to a buffer, linear_k / linear_v rows into the cache)
     int n_tail;
-    const float *lnt_g, *lnt_b;       // norm_mha
+    const float *lnt_g, *lnt_b;       // norm_mha / norm_conv
+    // single-contraction head instead of the FFN (attention output projection): Y = X + alpha * (A0 W^T + b2) with W = w2p packed
+    // [256][256]; A0 rows are staged as they are (no LayerNorm), w1p / b1 / ln_* unused
+    const float* A0;
     GemmP tg[3];
     const uint4* twp[3];
 };
@@ -310,7 +313,26 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
     float* fin = reinterpret_cast<float*>(ffn_smem);                            // [R][FFN_FLD] after the last contraction
     static_assert(R * FFN_FLD * 4 <= 2 * IMG + 4 * 16 * AS_SLD * 4, "result rows must fit the operand images + staging rows");
     // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
-    {
+    if (P.A0) {
+        constexpr int CJ = R * 32 / 256;                           // 8-float chunks per thread
+        float4 va[CJ], vb[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+            const float* ap = P.A0 + (long long)min(bm0 + r, P.M - 1) * RNNT_D + 8 * c;
+            va[j] = ldg4(ap);
+            vb[j] = ldg4(ap + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+            uint4 h, l;
+            split8_16<F16, LO>(va[j], vb[j], h, l);
+            const int off = op_off<NUM>(r, c);
+            *reinterpret_cast<uint4*>(Xop + off) = h;
+            if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
+        }
+    } else {
         constexpr int NP = R / 16;
         const int g = lane >> 4, l16 = lane & 15;
         float4 v[NP][4];
@@ -418,6 +440,18 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
 #pragma unroll
         for (int k = 0; k < KU; ++k) mma(acc, b[k], ks0 + k, op);
     };
+    if (P.A0) {
+        bload(b0[0], P.w2p, 8, wave, 0);
+        __syncthreads();                                            // Xop complete
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+            bload(b0[1], P.w2p, 8, wave, ks + 1);
+            mma(yacc, b0[0], ks, Xop);
+            if (ks + 2 < 8) bload(b0[0], P.w2p, 8, wave, ks + 2);
+            mma(yacc, b0[1], ks + 1, Xop);
+        }
+        __syncthreads();                                            // every wave is done with Xop
+    } else {
     uload(b0, 0, 0);
     __syncthreads();                                                // Xop complete
 #pragma unroll 1
@@ -476,6 +510,7 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             umma(yacc, b1, ks + KU, Hop);
         }
         __syncthreads();                                            // every wave is done with Hop (after the last slice: with Xop too)
+    }
     }
     // ---- result rows through LDS: residual, optional norm_final, float4 stores -------------------------------------------------------
 #pragma unroll
@@ -561,9 +596,13 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
         const unsigned char* Top = ffn_smem + FFN_TIMG;
         float* estage2 = reinterpret_cast<float*>(ffn_smem + FFN_TIMG + IMG) + wave * (16 * AS_SLD);
         __syncthreads();                                            // tail image complete
-        bload(b0[0], P.twp[0], 8, wave, 0);
-#pragma unroll 1
-        for (int gi = 0; gi < P.n_tail; ++gi) {
+        // (matrix, 64-column group) pairs of this wave, one after the other; the next pair's first unit is in flight across the epilogue
+        int gi = 0, grp = wave;
+        while (gi < P.n_tail && grp * 64 >= P.tg[gi].N) { ++gi; grp = wave; }
+        if (gi < P.n_tail) bload(b0[0], P.twp[gi], 8, grp, 0);
+        while (gi < P.n_tail) {
+            int ngi = gi, ngrp = grp + 4;
+            while (ngi < P.n_tail && ngrp * 64 >= P.tg[ngi].N) { ++ngi; ngrp = wave; }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -571,13 +610,14 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             const uint4* Wp = P.twp[gi];
 #pragma unroll
             for (int ks = 0; ks < 8; ks += 2) {
-                bload(b0[1], Wp, 8, wave, ks + 1);
+                bload(b0[1], Wp, 8, grp, ks + 1);
                 mma(hacc, b0[0], ks, Top);
-                if (ks + 2 < 8) bload(b0[0], Wp, 8, wave, ks + 2);
-                else if (gi + 1 < P.n_tail) bload(b0[0], P.twp[gi + 1], 8, wave, 0);
+                if (ks + 2 < 8) bload(b0[0], Wp, 8, grp, ks + 2);
+                else if (ngi < P.n_tail) bload(b0[0], P.twp[ngi], 8, ngrp, 0);
                 mma(hacc, b0[1], ks + 1, Top);
             }
-            as_epilogue<MT>(P.tg[gi], hacc, bm0, wave * 64, estage2, lane);
+            as_epilogue<MT>(P.tg[gi], hacc, bm0, grp * 64, estage2, lane);
+            gi = ngi; grp = ngrp;
         }
     }
 }
