@@ -53,6 +53,7 @@ struct rnnt_ctx {
     uint4* fuse_w = nullptr;
     size_t fuse_w_vecs = 0;
     LayerDev* layers_dev = nullptr;
+    const uint4* conv2_wp = nullptr;          // fragment-major packed conv2 weights of the current numerics mode (gemm_bw)
     std::vector<LayerDev> layers_host;        // host copy (packed-weight pointers for gemm_as / ffn_as launches)
     int use_as = 1;                            // RNNT_AS=0: LDS-tiled gemm_bf for every layer contraction of the layer-major schedule
     int use_fused = 1;                         // RNNT_FUSED=0: the unfused wavefront (11 launches per stage)

@@ -621,3 +621,107 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// gemm_bw: long-K contraction with N = 256 (conv2 implicit GEMM K = 2304, embed Linear K = 4864) -- 128 x 256 workgroup tile,
+// A through LDS (generalised GemmP addressing, planes formed while the tile is staged, two buffers), WEIGHTS NOT through LDS:
+// every wave owns 64 output columns and streams their fragments from L2 in packed order straight to registers, one k-step
+// ahead.  Against gemm_bf's 128 x 128 tile this halves the LDS write traffic (ds_write_b128 at ~79 B/clk/CU was as long as
+// the MFMAs), reads every A element from HBM once (N is not split) and gives each wave 96 MFMAs per 8 KiB of weights, which
+// is what the per-CU L2 fetch rate (~45 GB/s) can feed.  Same products and k order as gemm_bf.
+// ------------------------------------------------------------------------------------------------
+template <int NUM>
+__global__ __launch_bounds__(256) void gemm_bw(GemmP p, const uint4* __restrict__ wp) {
+    using C = FuseCfg<NUM>;
+    constexpr bool F16 = C::F16, LO = C::PLANES == 2;
+    constexpr int U = C::PLANES, MT = 8;
+    __shared__ uint4 Ah[2][512];
+    __shared__ uint4 Al[LO ? 2 : 1][LO ? 512 : 1];
+    __shared__ __attribute__((aligned(16))) float estage_all[4 * 16 * AS_SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int bm0 = blockIdx.x * 128;
+    if (bm0 >= p.M) return;
+    const int srow = tid >> 2, sc = tid & 3;
+    const float* ag[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ag[j] = p.A + a_row_off(p, min(bm0 + srow + 64 * j, p.M - 1));
+    const bool aplain = p.a_plain != 0;
+    const int KT = p.K >> 5;
+    // the A stream comes from HBM (1.09 GB for conv2): its loads run FOUR k-steps ahead of the MFMAs in a register ring
+    float4 ra[4][2][2];
+    auto gload = [&](float4 (&r)[2][2], int blk) {
+        const int kk = blk * 32 + 8 * sc;
+        const long long ko = aplain ? (long long)kk : a_k_off(p, kk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { r[j][0] = ldg4_nt(ag[j] + ko); r[j][1] = ldg4_nt(ag[j] + ko + 4); }   // streamed once: keep the weights in L2
+    };
+    auto lstore = [&](int buf, const float4 (&r)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rr = srow + 64 * j;
+            uint4 h, l;
+            split8_16<F16, LO>(r[j][0], r[j][1], h, l);
+            const int slot = rr * 4 + (sc ^ bf_swz(rr));
+            Ah[buf][slot] = h;
+            if constexpr (LO) Al[buf][slot] = l;
+        }
+    };
+    auto bload = [&](uint4 (&b)[4 * U], int kt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                typedef unsigned u32x4g_ __attribute__((ext_vector_type(4)));
+                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(wp + ((long long)((wave * 4 + t) * KT + kt) * U + u) * 64 + lane);
+                b[t * U + u] = make_uint4(v[0], v[1], v[2], v[3]);
+#else
+                b[t * U + u] = wp[((long long)((wave * 4 + t) * KT + kt) * U + u) * 64 + lane];
+#endif
+            }
+    };
+    f32x4_ acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    const int fsw = q ^ bf_swz(i);
+    auto mma = [&](int buf, const uint4 (&b)[4 * U]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int slot = (16 * mt + i) * 4 + fsw;
+            const uint4 ah = Ah[buf][slot];
+            uint4 al = ah;
+            if constexpr (LO) al = Al[buf][slot];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (LO) {
+                    acc[mt][t] = mfma16_<F16>(al, b[t * U], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(ah, b[t * U + 1], acc[mt][t]);
+                }
+                acc[mt][t] = mfma16_<F16>(ah, b[t * U], acc[mt][t]);
+            }
+        }
+    };
+    uint4 b0[4 * U], b1[4 * U];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gload(ra[k], k);                     // KT >= 4 and KT % 4 == 0 (host check)
+    bload(b0, 0);
+    lstore(0, ra[0]);
+    __syncthreads();
+    for (int blk = 0; blk < KT; blk += 4) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = blk + s;
+            // LDS buffer k & 1 holds A(k); ring slots (s+1..s+3) % 4 hold A(k+1..k+3); slot s is free again
+            // loads return in issue order: the weight fragments (needed next k-step) go first, the far-ahead A rows behind them
+            if (k + 1 < KT) { if (s & 1) bload(b0, k + 1); else bload(b1, k + 1); }
+            if (k + 4 < KT) gload(ra[s], k + 4);
+            if (s & 1) mma(1, b1); else mma(0, b0);
+            if (k + 1 < KT) lstore((s + 1) & 1, ra[(s + 1) & 3]);
+            __syncthreads();
+        }
+    }
+    as_epilogue<MT>(p, acc, bm0, wave * 64, estage_all + wave * (16 * AS_SLD), lane);
+}

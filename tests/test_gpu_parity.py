@@ -685,3 +685,19 @@ def test_weight_reload_invalidates_cached_launch_state(np_state_dict, monkeypatc
     sb.engine.load_state_dict(np_state_dict(1))
     assert sb.decode_script(x, 16, per_chunk_decode=True) == want_pc
     assert sb.decode_script(x, 16, pipelined=True) == want_wu
+
+
+def test_large_stream_count_whole_utterance(np_state_dict):
+    """More streams than the four-CUs-per-stream decoder can hold (n_streams x 4 > CUs): the whole-utterance call takes the
+    one-workgroup-per-stream resident decoder after the encoder, with more decoder workgroups than can be resident at once
+    (they do not wait on each other).  320 streams x 160 frames built from two golden utterances: every stream's tokens equal
+    the reference's for its utterance."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
+    syn = torch.from_numpy(T.synth_fbank(2, 1000))
+    n = 320
+    x = torch.stack([syn[i % 2, :1000] for i in range(n)]).cuda().contiguous()
+    sb = StreamingBatch(np_state_dict(0), n, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256, max_tokens=2048)
+    toks = sb.decode_script(x, 16, pipelined=True)
+    for i in range(n):
+        assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), i
