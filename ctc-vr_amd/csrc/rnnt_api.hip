@@ -124,7 +124,7 @@ struct rnnt_ctx {
     // layer-major schedule (host_lm.hip.inc): activations over all B*F rows of a call, per-layer linear post-GLU rows, one
     // subsampling slab, attention block table (reused while the plan and the entry state stay the same)
     int use_lm = 1;                            // RNNT_LM=0: wavefront schedule for every whole-utterance call
-    float *lm_h = nullptr, *lm_q = nullptr, *lm_a = nullptr, *lm_d = nullptr, *lm_g = nullptr, *lm_y1 = nullptr, *lm_y2 = nullptr;
+    float *lm_x = nullptr, *lm_h = nullptr, *lm_q = nullptr, *lm_a = nullptr, *lm_d = nullptr, *lm_g = nullptr, *lm_y1 = nullptr, *lm_y2 = nullptr;
     size_t lm_y1_cap = 0, lm_y2_cap = 0, lm_blocks_cap = 0;
     LmBlock* lm_blocks = nullptr;
     std::vector<LmBlock> lm_blocks_host;

@@ -38,6 +38,7 @@ struct LmAttnP {
     const LmBlock* blocks;
     int F;
     long long kv_stride;
+    const int* klen;     // per-stream number of valid keys counted from a unit's kv_start (full-context padding mask); null = no limit
 };
 #define LM_ATT_LDS ((64 * ATT_LD + (64 + LM_PEXT) * ATT_LD + 64 * RNNT_DK + 3 * LM_NW * 4 * RNNT_DK) * 4)
 __global__ __launch_bounds__(64 * LM_NW) void rel_attention_lm(LmAttnP P) {
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(64 * LM_NW) void rel_attention_lm(LmAttnP P) {
     if (wave < n_units) {
         f0 = ldgi(&blk->u[wave].f0); nq = ldgi(&blk->u[wave].nq);
         ks = ldgi(&blk->u[wave].kv_start); ke = ks + ldgi(&blk->u[wave].T2);
+        if (P.klen) ke = min(ke, ks + ldgi(P.klen + b));
         prel = ldgi(&blk->u[wave].pshift) - pmin;     // 0 .. LM_PEXT
     }
     for (int e = tid; e < LM_NW * 4 * RNNT_DK; e += 64 * LM_NW) {
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
         s_ks[uu] = 0; s_ke[uu] = 0; s_prel[uu] = 0;
         if (u < n_units) {
             s_ks[uu] = ldgi(&blk->u[u].kv_start); s_ke[uu] = s_ks[uu] + ldgi(&blk->u[u].T2);
+            if (P.klen) s_ke[uu] = min(s_ke[uu], s_ks[uu] + ldgi(P.klen + b));
             s_prel[uu] = ldgi(&blk->u[u].pshift) - pmin;
         }
     }

@@ -663,7 +663,7 @@ def test_full_context_long_utterance(np_state_dict, numerics):
     x1 = xs[0:1].cuda().contiguous()
     assert eng.encoder_full(x1.data_ptr(), lens[:1], 1, Tn, one.data_ptr(), s) == tq
     torch.cuda.synchronize()
-    assert maxdiff(one.cpu().numpy()[0], o[0]) < 1e-5                                       # B = 1 call == its slot in the batch of 32
+    assert maxdiff(one.cpu().numpy()[0], o[0]) < 1e-4      # B = 1 call (M = 749 rows: other GEMM kernels, other summation order) ~ its slot in the batch of 32
 
 
 def test_weight_reload_invalidates_cached_launch_state(np_state_dict, monkeypatch):
