@@ -9,7 +9,7 @@ B, STEPS = 64, 6
 sd = T.make_state_dict(0, blank_bias=12.0)
 x = torch.from_numpy(T.synth_fbank(B, 1000)).cuda().contiguous()
 def make():
-    return StreamingBatch(sd, B, max_chunk_frames=24, max_cache_frames=200, max_enc_frames=200, max_tokens=1900)
+    return StreamingBatch(sd, B, max_chunk_frames=24, max_cache_frames=200, max_enc_frames=200, max_tokens=1900, numerics="bf16x3")
 def worker(sb, n, out):
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
