@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--site", default="auto", help="launch site timed in the timed region (auto = the one with the largest summed launch time)")
     ap.add_argument("--cpu-streams", type=int, default=8, help="streams of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--cpu-threads", type=int, default=8)
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                     help="batches in flight per GPU in the timed region: 2 = two contexts driven by two host threads, so one batch's latency-bound decode "
                          "runs beside the other's encoder (every step is still one whole batch; the single-batch latency is reported beside it)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -334,13 +334,14 @@ def main():
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------------------------------------
     import threading
     nfl = args.in_flight if args.steps >= 8 else 1              # fewer steps than that cannot fill the two-context pipeline
-    sb2 = None
-    if nfl == 2:
-        sb2 = make_sb(choice)
-        sb2.decode_script(x, args.chunk, pipelined=True)         # first call (allocations, tables) outside the timed region
-        torch.cuda.synchronize()
-    share = [args.steps - args.steps // 2, args.steps // 2] if nfl == 2 else [args.steps]
-    results = [None, None]
+    ctxs = [sb]
+    for _ in range(nfl - 1):
+        sbk = make_sb(choice)
+        sbk.decode_script(x, args.chunk, pipelined=True)         # first call (allocations, tables) outside the timed region
+        ctxs.append(sbk)
+    torch.cuda.synchronize()
+    share = [args.steps // nfl + (1 if k < args.steps % nfl else 0) for k in range(nfl)]
+    results = [None] * nfl
 
     wstreams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     gate = threading.Barrier(sum(1 for k in range(nfl) if share[k] > 0) + 1)
@@ -352,7 +353,7 @@ def main():
                 results[idx] = sbk.decode_script(x, args.chunk, pipelined=True)
         wstreams[idx].synchronize()
 
-    threads = [threading.Thread(target=worker, args=(k, (sb, sb2)[k], share[k])) for k in range(nfl) if share[k] > 0]
+    threads = [threading.Thread(target=worker, args=(k, ctxs[k], share[k])) for k in range(nfl) if share[k] > 0]
     for th in threads:
         th.start()
     if world > 1:
