@@ -701,3 +701,35 @@ def test_large_stream_count_whole_utterance(np_state_dict):
     toks = sb.decode_script(x, 16, pipelined=True)
     for i in range(n):
         assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), i
+
+
+def test_two_contexts_in_flight(np_state_dict):
+    """Two contexts driven by two host threads on two HIP streams at the same time (how bench.py keeps two batches in flight:
+    one batch's decode beside the other's encoder; include/rnnt_hip.h: distinct contexts are independent, one host thread
+    per context at a time): every pass of either context returns the reference's tokens."""
+    import threading
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
+    syn = torch.from_numpy(T.synth_fbank(2, 1000))
+    n = 16
+    x = torch.stack([syn[i % 2] for i in range(n)]).cuda().contiguous()
+    want = [(g0, g1)[i % 2]["tokens"].tolist() for i in range(n)]
+    sbs = [StreamingBatch(np_state_dict(0), n, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256, max_tokens=2048) for _ in range(2)]
+    for sb in sbs:
+        assert sb.decode_script(x, 16, pipelined=True) == want
+    torch.cuda.synchronize()
+    bad, streams = [], [torch.cuda.Stream() for _ in range(2)]
+
+    def worker(k):
+        with torch.cuda.stream(streams[k]):
+            for it in range(6):
+                if sbs[k].decode_script(x, 16, pipelined=True) != want:
+                    bad.append((k, it))
+        streams[k].synchronize()
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
