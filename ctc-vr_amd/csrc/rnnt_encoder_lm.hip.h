@@ -10,22 +10,21 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------
-// rel_attention_lm: RelPositionMultiHeadedAttention scores / softmax / PV (attention.py:400-418,170-177) for ALL chunks of a
-// call.  A "unit" is up to 4 consecutive query frames of one chunk; its keys are the absolute cache rows
-// [kv_start, kv_start + T2) of the stream and the positional row of cache row a is a + pshift (pshift = pos_start - kv_start:
-// encoder.py:257 rebuilt per chunk, no rel_shift).  A workgroup = LM_NW waves = LM_NW units of consecutive chunks and one
-// (stream, head): K / V / positional rows are staged ONCE per 64-key tile for all its units (the chunk-by-chunk kernels re-read
-// the whole cache for every chunk: 9.3 GB per 64 x 10 s batch; here ~1/8 of that).  Scores with lane = key, online softmax per
-// unit, PV with lane = d.  The units' positional windows differ by a few rows: the positional tile carries LM_PEXT extra rows.
+// Attention of ALL chunks of a call (RelPositionMultiHeadedAttention scores / softmax / PV, attention.py:400-418,170-177).
+// Every query frame is a ROW with its own key window: the absolute cache rows [ks, ke) of its stream that the chunk-by-chunk
+// loop would have cached for its chunk, and the positional row of cache row a is a + pshift (pshift = pos_start - kv_start:
+// encoder.py:257 rebuilt per chunk, no rel_shift).  A workgroup takes LM_ROWS consecutive rows (about ten 3-frame chunks) and one
+// (stream, head): K / V / positional rows are staged ONCE per 64-key tile for all of them (the chunk-by-chunk kernels re-read
+// the whole cache for every chunk: 9.3 GB per 64 x 10 s batch).  The rows' positional windows differ by a few rows: the
+// positional tile carries LM_PEXT extra rows.  Kernel: rel_attention_lm_mfma below.
 //   q, out  [B*F][256] stream-major rows (b*F + f);  kc, vc [B][kv_stride][256];  ptab [5000][256] of this layer
-// grid = (B*H, n_blocks), block = 64*LM_NW, dynamic LDS = LM_ATT_LDS bytes.
 // ------------------------------------------------------------------------------------------------
-#define LM_NW 8
+#define LM_ROWS 32
 #define LM_PEXT 16
-struct LmUnit { int f0, nq, kv_start, T2, pshift; };
+struct LmRow { int f, ks, ke, pshift; };   // f < 0: unused slot
 struct LmBlock {
-    int n_units, amin, amax, pmin;     // key rows [amin, amax) cover every unit; pmin = smallest pshift
-    LmUnit u[LM_NW];
+    int n_rows, amin, amax, pmin;          // key rows [amin, amax) cover every row's window; pmin = smallest pshift
+    LmRow r[LM_ROWS];
 };
 struct LmAttnP {
     const float* q;
@@ -38,112 +37,8 @@ struct LmAttnP {
     const LmBlock* blocks;
     int F;
     long long kv_stride;
-    const int* klen;     // per-stream number of valid keys counted from a unit's kv_start (full-context padding mask); null = no limit
+    const int* klen;     // per-stream number of valid keys counted from a row's ks (full-context padding mask); null = no limit
 };
-#define LM_ATT_LDS ((64 * ATT_LD + (64 + LM_PEXT) * ATT_LD + 64 * RNNT_DK + 3 * LM_NW * 4 * RNNT_DK) * 4)
-__global__ __launch_bounds__(64 * LM_NW) void rel_attention_lm(LmAttnP P) {
-    extern __shared__ __attribute__((aligned(16))) float lm_smem[];
-    float* Ks = lm_smem;                              // [64][ATT_LD]
-    float* Ps = Ks + 64 * ATT_LD;                     // [64 + PEXT][ATT_LD]
-    float* Vs = Ps + (64 + LM_PEXT) * ATT_LD;         // [64][64]
-    float* Qu = Vs + 64 * RNNT_DK;                    // [NW][4][64]
-    float* Qv = Qu + LM_NW * 4 * RNNT_DK;
-    float* Pm = Qv + LM_NW * 4 * RNNT_DK;             // [NW][4][64]
-    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const LmBlock* __restrict__ blk = P.blocks + blockIdx.y;
-    const int n_units = ldgi(&blk->n_units), amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
-    int f0 = 0, nq = 0, ks = 0, ke = 0, prel = 0;
-    if (wave < n_units) {
-        f0 = ldgi(&blk->u[wave].f0); nq = ldgi(&blk->u[wave].nq);
-        ks = ldgi(&blk->u[wave].kv_start); ke = ks + ldgi(&blk->u[wave].T2);
-        if (P.klen) ke = min(ke, ks + ldgi(P.klen + b));
-        prel = ldgi(&blk->u[wave].pshift) - pmin;     // 0 .. LM_PEXT
-    }
-    for (int e = tid; e < LM_NW * 4 * RNNT_DK; e += 64 * LM_NW) {
-        const int w = e >> 8, iq = (e >> 6) & 3, d = e & 63;
-        float qq = 0.f;
-        if (w < n_units && iq < ldgi(&blk->u[w].nq))
-            qq = ldg1(P.q + ((long long)b * P.F + ldgi(&blk->u[w].f0) + iq) * RNNT_D + h * RNNT_DK + d);
-        Qu[e] = qq + ldg1(P.bias_u + h * RNNT_DK + d);
-        Qv[e] = qq + ldg1(P.bias_v + h * RNNT_DK + d);
-    }
-    float mrun[4], lrun[4], o[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { mrun[s] = -INFINITY; lrun[s] = 0.f; o[s] = 0.f; }
-    const float* kbase = P.kc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
-    const float* vbase = P.vc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
-    const float* pbase = P.ptab + h * RNNT_DK;
-    for (int a0 = amin; a0 < amax; a0 += 64) {
-        __syncthreads();
-        for (int e = tid; e < 64 * 16; e += 64 * LM_NW) {
-            const int r = e >> 4, c4 = e & 15;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (a0 + r < amax) {
-                kv = ldg4(kbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
-                vv = ldg4(vbase + (long long)(a0 + r) * RNNT_D + c4 * 4);
-            }
-            *reinterpret_cast<float4*>(&Ks[r * ATT_LD + c4 * 4]) = kv;
-            *reinterpret_cast<float4*>(&Vs[r * RNNT_DK + c4 * 4]) = vv;
-        }
-        for (int e = tid; e < (64 + LM_PEXT) * 16; e += 64 * LM_NW) {
-            const int r = e >> 4, c4 = e & 15;
-            const int pr = a0 + pmin + r;
-            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pr >= 0 && pr < RNNT_PE_LEN) pv = ldg4(pbase + (long long)pr * RNNT_D + c4 * 4);
-            *reinterpret_cast<float4*>(&Ps[r * ATT_LD + c4 * 4]) = pv;
-        }
-        __syncthreads();
-        if (nq == 0 || a0 >= ke || a0 + 64 <= ks) continue;        // wave-uniform: this unit has no key in the tile
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* krow = Ks + lane * ATT_LD;
-        const float* prow = Ps + (lane + prel) * ATT_LD;
-        const float* qu = Qu + wave * 4 * RNNT_DK;
-        const float* qv = Qv + wave * 4 * RNNT_DK;
-#pragma unroll 4
-        for (int dc = 0; dc < 16; ++dc) {
-            const float4 k4 = *reinterpret_cast<const float4*>(krow + dc * 4);
-            const float4 p4 = *reinterpret_cast<const float4*>(prow + dc * 4);
-#pragma unroll
-            for (int iq = 0; iq < 4; ++iq) {
-                const float4 u4 = *reinterpret_cast<const float4*>(qu + iq * RNNT_DK + dc * 4);
-                const float4 v4 = *reinterpret_cast<const float4*>(qv + iq * RNNT_DK + dc * 4);
-                float t = s[iq];
-                t = fmaf(u4.x, k4.x, t); t = fmaf(u4.y, k4.y, t); t = fmaf(u4.z, k4.z, t); t = fmaf(u4.w, k4.w, t);
-                t = fmaf(v4.x, p4.x, t); t = fmaf(v4.y, p4.y, t); t = fmaf(v4.z, p4.z, t); t = fmaf(v4.w, p4.w, t);
-                s[iq] = t;
-            }
-        }
-        const int a = a0 + lane;
-        const bool valid = a >= ks && a < ke;
-        float alpha[4];
-        float* pm = Pm + wave * 4 * 64;
-#pragma unroll
-        for (int iq = 0; iq < 4; ++iq) {
-            const float sc = valid ? s[iq] * 0.125f : -INFINITY;
-            const float mnew = fmaxf(mrun[iq], wave_max(sc));     // finite: the tile holds at least one valid key
-            const float pe_ = valid ? expf(sc - mnew) : 0.f;
-            alpha[iq] = expf(mrun[iq] - mnew);                    // first tile: exp(-inf) = 0
-            lrun[iq] = lrun[iq] * alpha[iq] + wave_sum(pe_);
-            mrun[iq] = mnew;
-            pm[iq * 64 + lane] = pe_;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                           // pm rows are private to the wave
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int iq = 0; iq < 4; ++iq) o[iq] *= alpha[iq];
-        const int j0 = max(ks - a0, 0), j1 = min(ke - a0, 64);
-        for (int j = j0; j < j1; ++j) {
-            const float vj = Vs[j * RNNT_DK + lane];
-#pragma unroll
-            for (int iq = 0; iq < 4; ++iq) o[iq] = fmaf(pm[iq * 64 + j], vj, o[iq]);
-        }
-    }
-#pragma unroll
-    for (int iq = 0; iq < 4; ++iq)
-        if (iq < nq) stg1(P.out + ((long long)b * P.F + f0 + iq) * RNNT_D + h * RNNT_DK + lane, o[iq] / lrun[iq]);
-}
 
 // ------------------------------------------------------------------------------------------------
 // lm_ctx_in: the 30-row left context of every layer's linear post-GLU buffer <- the stream's ring rows before `pos`
@@ -249,23 +144,21 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
     const int i = lane & 15, kq = lane >> 4;
     const int qt = wave & 1, hf = wave >> 1;
     const LmBlock* __restrict__ blk = P.blocks + blockIdx.y;
-    const int n_units = ldgi(&blk->n_units), amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
-    // softmax role: query slots 8*wave .. +7 = units 2*wave, 2*wave + 1
-    int s_ks[2], s_ke[2], s_prel[2];
+    const int amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
+    // softmax role: rows 8*wave .. +7, each with its own key window
+    int s_ks[8], s_ke[8], s_prel[8];
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-        const int u = 2 * wave + uu;
-        s_ks[uu] = 0; s_ke[uu] = 0; s_prel[uu] = 0;
-        if (u < n_units) {
-            s_ks[uu] = ldgi(&blk->u[u].kv_start); s_ke[uu] = s_ks[uu] + ldgi(&blk->u[u].T2);
-            if (P.klen) s_ke[uu] = min(s_ke[uu], s_ks[uu] + ldgi(P.klen + b));
-            s_prel[uu] = ldgi(&blk->u[u].pshift) - pmin;
+    for (int j = 0; j < 8; ++j) {
+        const LmRow* rw = &blk->r[8 * wave + j];
+        s_ks[j] = 0; s_ke[j] = 0; s_prel[j] = 0;
+        if (ldgi(&rw->f) >= 0) {
+            s_ks[j] = ldgi(&rw->ks); s_ke[j] = ldgi(&rw->ke);
+            if (P.klen) s_ke[j] = min(s_ke[j], s_ks[j] + ldgi(P.klen + b));
+            s_prel[j] = ldgi(&rw->pshift) - pmin;
         }
     }
-    // contraction role: this lane's query row 16*qt + i = (unit 4*qt + i/4, slot i % 4)
-    const int my_u = 4 * qt + (i >> 2), my_iq = i & 3;
-    int my_f = -1;
-    if (my_u < n_units && my_iq < ldgi(&blk->u[my_u].nq)) my_f = ldgi(&blk->u[my_u].f0) + my_iq;
+    // contraction role: this lane's query row 16*qt + i
+    const int my_f = ldgi(&blk->r[16 * qt + i].f);
     float4 qu[4], qv[4];
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) {
@@ -356,15 +249,15 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
         //      row inner): eight independent cross-lane exchanges per step instead of 96 dependent ones ---------------------------------
         {
             float sc[8], mx[8], pe_[8], sm[8];
-            bool live[2];
+            bool live[8];
 #pragma unroll
-            for (int uu = 0; uu < 2; ++uu) live[uu] = a0 < s_ke[uu] && a0 + 64 > s_ks[uu];   // wave-uniform
+            for (int j = 0; j < 8; ++j) live[j] = a0 < s_ke[j] && a0 + 64 > s_ks[j];   // wave-uniform
             const int a = a0 + lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int qs = 8 * wave + j, uu = j >> 2;
-                const bool valid = live[uu] && a >= s_ks[uu] && a < s_ke[uu];
-                sc[j] = valid ? (Sx[qs * LM2_LD + lane] + Gx[qs * LM2_GLD + lane + s_prel[uu]]) * 0.125f : -INFINITY;
+                const int qs = 8 * wave + j;
+                const bool valid = live[j] && a >= s_ks[j] && a < s_ke[j];
+                sc[j] = valid ? (Sx[qs * LM2_LD + lane] + Gx[qs * LM2_GLD + lane + s_prel[j]]) * 0.125f : -INFINITY;
                 mx[j] = sc[j];
             }
 #pragma unroll
@@ -376,8 +269,8 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
                 const float mnew = fmaxf(mrun[j], mx[j]);
                 pe_[j] = sc[j] > -INFINITY ? expf(sc[j] - mnew) : 0.f;
                 sm[j] = pe_[j];
-                mx[j] = live[j >> 2] ? expf(mrun[j] - mnew) : 1.0f;          // alpha (first live tile: exp(-inf) = 0)
-                if (live[j >> 2]) mrun[j] = mnew;
+                mx[j] = live[j] ? expf(mrun[j] - mnew) : 1.0f;               // alpha (first live tile: exp(-inf) = 0)
+                if (live[j]) mrun[j] = mnew;
             }
 #pragma unroll
             for (int o_ = 32; o_ > 0; o_ >>= 1)
@@ -419,10 +312,10 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = 16 * qt + 4 * kq + r;                       // query slot of accumulator row r
-        const int u = row >> 2, iq = row & 3;
-        if (u < n_units && iq < ldgi(&blk->u[u].nq)) {
-            const long long m = (long long)b * P.F + ldgi(&blk->u[u].f0) + iq;
+        const int row = 16 * qt + 4 * kq + r;                       // query row of accumulator register r
+        const int fr = ldgi(&blk->r[row].f);
+        if (fr >= 0) {
+            const long long m = (long long)b * P.F + fr;
             const float li = al[row];
 #pragma unroll
             for (int dd = 0; dd < 2; ++dd) stg1(P.out + m * RNNT_D + h * RNNT_DK + 16 * (2 * hf + dd) + i, o[dd][r] * li);
