@@ -102,10 +102,12 @@ int rnnt_encoder_chunk(rnnt_ctx* ctx, const float* fbank_dev, int32_t chunk_fram
 /* replaces the whole chunk loop around forward_chunk (online_rnnt_decode.py:87-117, or streaming_inference,
  * model/online_rnnt_model.py:311-342) for utterances that are fully available: chunk c of every stream covers fbank
  * frames [chunk_start[c], chunk_start[c]+chunk_len[c]) and is encoded with (offsets[c], required[c]) exactly as
- * n_chunks calls of rnnt_encoder_chunk would (same float32 arithmetic up to summation order), scheduled as a wavefront over
- * (chunk, layer) with batched subsampling.  fbank_dev [n_streams, total_frames, 80]; host int arrays.
- * greedy != 0: the greedy decode of rnnt_greedy_decode runs concurrently on an internal stream, consuming each
- * chunk's frames as soon as they exist; the call then returns with all frames decoded (synchronises). */
+ * n_chunks calls of rnnt_encoder_chunk would (same float32 arithmetic up to summation order).  Schedule: layer-major -- each
+ * of the 12 blocks runs over all chunks at once (one GEMM over streams x frames rows per contraction; every query keeps its
+ * own chunk's key window and positional window); plans with a cache reset in the middle of the call take the wavefront over
+ * (chunk, layer) instead.  fbank_dev [n_streams, total_frames, 80]; host int arrays.
+ * greedy != 0: the greedy decode of rnnt_greedy_decode follows on the same stream; the call returns with all frames
+ * decoded (synchronises).  Two contexts driven by two host threads overlap one call's decode with the other's encoder. */
 int rnnt_encoder_chunks(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_frames, int32_t n_chunks,
                         const int32_t* chunk_start, const int32_t* chunk_len, const int32_t* offsets,
                         const int32_t* required, int32_t greedy, int32_t* frames_out, void* stream);
@@ -176,7 +178,8 @@ int rnnt_joint(rnnt_ctx* ctx, const float* enc_dev, const float* pred_dev, int32
 
 /* replaces BaseEncoder.forward(xs, lens, decoding_chunk_size=-1) (full context,
  * wenet/transformer/encoder.py:121-180).  fbank_dev [B,T,80], lens_host[B];
- * out_dev [B,T',256]; *frames_out = T'. */
+ * out_dev [B,T',256]; *frames_out = T'.  Runs as the layer-major schedule with ONE chunk of T frames (all valid keys at
+ * positional window 0, per-stream padding mask); invalidates the streaming state. */
 int rnnt_encoder_full(rnnt_ctx* ctx, const float* fbank_dev, const int32_t* lens_host, int32_t B,
                       int32_t T, float* out_dev, int32_t* frames_out, void* stream);
 
