@@ -333,7 +333,7 @@ def main():
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks -------------------------------------
     import threading
-    nfl = args.in_flight if args.steps >= 8 else 1              # fewer steps than that cannot fill the two-context pipeline
+    nfl = args.in_flight if args.steps >= 6 else 1              # fewer steps than that cannot fill the two-context pipeline
     ctxs = [sb]
     for _ in range(nfl - 1):
         sbk = make_sb(choice)
