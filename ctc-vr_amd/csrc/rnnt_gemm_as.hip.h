@@ -32,25 +32,26 @@ struct AsBatch {
 // float4 per lane (16 lanes = one row's 256 contiguous bytes); bias / activation / residual / GLU are applied on the float4,
 // so every global access of the epilogue is 16 bytes per lane (8 for the halved GLU rows).  Row addressing = c_row_off.
 #define AS_SLD 68
-template <int MT>
-__device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[MT][4], int m0, int n0, float* stage, int lane) {
+template <int MT, int NTW = 4>
+__device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[MT][NTW], int m0, int n0, float* stage, int lane) {
+    constexpr int LPR = 4 * NTW, RPP = 64 / LPR;                   // lanes per row (float4 each), rows per read-back pass
     const int i = lane & 15, q = lane >> 4;
     const int epi = p.epi;
-    const int c4 = (lane & 15) * 4, n = n0 + c4;
+    const int c4 = (lane % LPR) * 4, n = n0 + c4;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bias = ldg4(p.bias + n);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stage[(4 * q + r) * AS_SLD + 16 * t + i] = acc[mt][t][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rr = (lane >> 4) + 4 * j;
+        for (int j = 0; j < 16 / RPP; ++j) {
+            const int rr = lane / LPR + RPP * j;
             const int m = m0 + 16 * mt + rr;
             float4 v = *reinterpret_cast<const float4*>(&stage[rr * AS_SLD + c4]);
             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
@@ -296,9 +297,12 @@ struct FfnP {
 #ifndef FFN_KU
 #define FFN_KU 2
 #endif
-#define FFN_LDS(NUM_) ((size_t)FFN_TIMG + (size_t)FuseCfg<NUM_>::PLANES * 16 * AS_MT_ * FuseCfg<NUM_>::ROWB + 4 * 16 * AS_SLD * 4)
-template <int NUM, int MT>
-__global__ __launch_bounds__(256) void ffn_as(FfnP P) {
+#define FFN_LDS(NUM_, NW_) ((size_t)FFN_TIMG + (size_t)FuseCfg<NUM_>::PLANES * 16 * AS_MT_ * FuseCfg<NUM_>::ROWB + (NW_) * 16 * AS_SLD * 4)
+// NW waves per workgroup (4 or 8): every wave owns 256 / NW of the 256 output columns of a contraction (NTW = 16 / NW column
+// tiles).  NW = 8 puts two waves on every SIMD, so one wave's waits on weight fragments hide under the other's MFMAs.
+template <int NUM, int MT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
+    constexpr int NTW = 16 / NW, CW = 16 * NTW, NT = 64 * NW;
     using C = FuseCfg<NUM>;
     constexpr bool F16 = C::F16, LO = C::PLANES == 2;
     constexpr int U = C::PLANES, R = 16 * MT, ROWB = C::ROWB, IMG = U * R * ROWB;
@@ -311,21 +315,21 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
     if (bm0 >= P.M) return;
     float* estage = reinterpret_cast<float*>(ffn_smem + 2 * IMG) + wave * (16 * AS_SLD);
     float* fin = reinterpret_cast<float*>(ffn_smem);                            // [R][FFN_FLD] after the last contraction
-    static_assert(R * FFN_FLD * 4 <= 2 * IMG + 4 * 16 * AS_SLD * 4, "result rows must fit the operand images + staging rows");
+    static_assert(R * FFN_FLD * 4 <= 2 * IMG + NW * 16 * AS_SLD * 4, "result rows must fit the operand images + staging rows");
     // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
     if (P.A0) {
-        constexpr int CJ = R * 32 / 256;                           // 8-float chunks per thread
+        constexpr int CJ = R * 32 / NT;                            // 8-float chunks per thread
         float4 va[CJ], vb[CJ];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-            const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+            const int e = tid + NT * j, r = e >> 5, c = e & 31;
             const float* ap = P.A0 + (long long)min(bm0 + r, P.M - 1) * RNNT_D + 8 * c;
             va[j] = ldg4(ap);
             vb[j] = ldg4(ap + 4);
         }
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-            const int e = tid + 256 * j, r = e >> 5, c = e & 31;
+            const int e = tid + NT * j, r = e >> 5, c = e & 31;
             uint4 h, l;
             split8_16<F16, LO>(va[j], vb[j], h, l);
             const int off = op_off<NUM>(r, c);
@@ -333,12 +337,12 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
         }
     } else {
-        constexpr int NP = R / 16;
+        constexpr int RP = 4 * NW, NP = (R + RP - 1) / RP;         // rows per pass (4 per wave), passes
         const int g = lane >> 4, l16 = lane & 15;
         float4 v[NP][4];
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
-            const float* rp = P.X + (long long)min(bm0 + wave * 4 + g + 16 * ps, P.M - 1) * RNNT_D;
+            const float* rp = P.X + (long long)min(bm0 + min(wave * 4 + g + RP * ps, R - 1), P.M - 1) * RNNT_D;
 #pragma unroll
             for (int j = 0; j < 2; ++j) { v[ps][2 * j] = ldg4(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = ldg4(rp + 8 * (l16 + 16 * j) + 4); }
         }
@@ -370,7 +374,8 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             const float4 g0 = ldg4(P.ln_g + 8 * c), g1 = ldg4(P.ln_g + 8 * c + 4), b0_ = ldg4(P.ln_b + 8 * c), b1_ = ldg4(P.ln_b + 8 * c + 4);
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
-                const int r = wave * 4 + g + 16 * ps;
+                const int r = wave * 4 + g + RP * ps;
+                if (r >= R) continue;
                 const float m_ = mu[ps], s_ = rs[ps];
                 float4 x0 = v[ps][2 * j], x1 = v[ps][2 * j + 1];
                 x0.x = (x0.x - m_) * s_ * g0.x + b0_.x; x0.y = (x0.y - m_) * s_ * g0.y + b0_.y; x0.z = (x0.z - m_) * s_ * g0.z + b0_.z; x0.w = (x0.w - m_) * s_ * g0.w + b0_.w;
@@ -383,21 +388,21 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             }
         }
     }
-    auto bload = [&](uint4 (&b)[4 * U], const uint4* __restrict__ Wp, int KT, int grp, int kt) {
+    auto bload = [&](uint4 (&b)[NTW * U], const uint4* __restrict__ Wp, int KT, int ct0 /*first column tile*/, int kt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 typedef unsigned u32x4g_ __attribute__((ext_vector_type(4)));
-                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(Wp + ((long long)((grp * 4 + t) * KT + kt) * U + u) * 64 + lane);
+                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(Wp + ((long long)((ct0 + t) * KT + kt) * U + u) * 64 + lane);
                 b[t * U + u] = make_uint4(v[0], v[1], v[2], v[3]);
 #else
-                b[t * U + u] = Wp[((long long)((grp * 4 + t) * KT + kt) * U + u) * 64 + lane];
+                b[t * U + u] = Wp[((long long)((ct0 + t) * KT + kt) * U + u) * 64 + lane];
 #endif
             }
     };
-    auto mma = [&](f32x4_ (&acc)[MT][4], const uint4 (&b)[4 * U], int ks, const unsigned char* op) {
+    auto mma = [&](f32x4_ (&acc)[MT][NTW], const uint4 (&b)[NTW * U], int ks, const unsigned char* op) {
         uint4 ah[MT], al[LO ? MT : 1];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             if constexpr (LO) al[mt] = *reinterpret_cast<const uint4*>(rp + R * ROWB);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (LO) {
@@ -417,37 +422,37 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    f32x4_ yacc[MT][4], hacc[MT][4];
+    f32x4_ yacc[MT][NTW], hacc[MT][NTW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t) yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
     // Weight stream: per 256 hidden columns c, 8 k-steps of w_1's column group 4c + wave, then 8 k-steps of w_2's K slice c for
     // this wave's 64 output columns.  A pipeline unit = FFN_KU k-steps (8 KiB per wave each); one unit is consumed while the
     // next is in flight, across the hidden-slice epilogue and the barriers.  The kernel runs at the per-CU L2 fetch rate, which
     // is set by the bytes in flight.
     constexpr int KU = FFN_KU;
-    uint4 b0[KU][4 * U], b1[KU][4 * U];
-    auto uload = [&](uint4 (&b)[KU][4 * U], int phase /*2c: w_1, 2c+1: w_2*/, int ks0) {
+    uint4 b0[KU][NTW * U], b1[KU][NTW * U];
+    auto uload = [&](uint4 (&b)[KU][NTW * U], int phase /*2c: w_1, 2c+1: w_2*/, int ks0) {
         const int c = phase >> 1;
 #pragma unroll
         for (int k = 0; k < KU; ++k) {
-            if (phase & 1) bload(b[k], P.w2p, 32, wave, c * 8 + ks0 + k);
-            else bload(b[k], P.w1p, 8, c * 4 + wave, ks0 + k);
+            if (phase & 1) bload(b[k], P.w2p, 32, wave * NTW, c * 8 + ks0 + k);
+            else bload(b[k], P.w1p, 8, c * 16 + wave * NTW, ks0 + k);
         }
     };
-    auto umma = [&](f32x4_ (&acc)[MT][4], const uint4 (&b)[KU][4 * U], int ks0, const unsigned char* op) {
+    auto umma = [&](f32x4_ (&acc)[MT][NTW], const uint4 (&b)[KU][NTW * U], int ks0, const unsigned char* op) {
 #pragma unroll
         for (int k = 0; k < KU; ++k) mma(acc, b[k], ks0 + k, op);
     };
     if (P.A0) {
-        bload(b0[0], P.w2p, 8, wave, 0);
+        bload(b0[0], P.w2p, 8, wave * NTW, 0);
         __syncthreads();                                            // Xop complete
 #pragma unroll
         for (int ks = 0; ks < 8; ks += 2) {
-            bload(b0[1], P.w2p, 8, wave, ks + 1);
+            bload(b0[1], P.w2p, 8, wave * NTW, ks + 1);
             mma(yacc, b0[0], ks, Xop);
-            if (ks + 2 < 8) bload(b0[0], P.w2p, 8, wave, ks + 2);
+            if (ks + 2 < 8) bload(b0[0], P.w2p, 8, wave * NTW, ks + 2);
             mma(yacc, b0[1], ks + 1, Xop);
         }
         __syncthreads();                                            // every wave is done with Xop
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NTW; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 8; ks += 2 * KU) {
             uload(b1, 2 * c, ks + KU);
@@ -470,21 +475,22 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
         }
         {
             // hidden columns c*256 + wave*64 .. +64 = silu(acc + b1) -> Hop (through the wave's staging rows: 8-float chunks)
-            const int rr0 = lane >> 3, c8 = lane & 7;
-            const float* bp = P.b1 + c * 256 + wave * 64 + 8 * c8;
+            constexpr int LPR = CW / 8, HRP = 64 / LPR;              // lanes per row (8 columns each), rows per pass
+            const int rr0 = lane / LPR, c8 = lane % LPR;
+            const float* bp = P.b1 + c * 256 + wave * CW + 8 * c8;
             const float4 ba = ldg4(bp), bq = ldg4(bp + 4);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < NTW; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) estage[(4 * q + r) * AS_SLD + 16 * t + i] = hacc[mt][t][r];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int rr = rr0 + 8 * ps;
+                for (int ps = 0; ps < 16 / HRP; ++ps) {
+                    const int rr = rr0 + HRP * ps;
                     float4 x0 = *reinterpret_cast<const float4*>(&estage[rr * AS_SLD + 8 * c8]);
                     float4 x1 = *reinterpret_cast<const float4*>(&estage[rr * AS_SLD + 8 * c8 + 4]);
                     x0.x += ba.x; x0.y += ba.y; x0.z += ba.z; x0.w += ba.w; x1.x += bq.x; x1.y += bq.y; x1.z += bq.z; x1.w += bq.w;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
                     x1.x *= sigmoidf_(x1.x); x1.y *= sigmoidf_(x1.y); x1.z *= sigmoidf_(x1.z); x1.w *= sigmoidf_(x1.w);
                     uint4 h, l;
                     split8_16<F16, LO>(x0, x1, h, l);
-                    const int off = op_off<NUM>(16 * mt + rr, wave * 8 + c8);
+                    const int off = op_off<NUM>(16 * mt + rr, wave * LPR + c8);
                     *reinterpret_cast<uint4*>(Hop + off) = h;
                     if constexpr (LO) *reinterpret_cast<uint4*>(Hop + R * ROWB + off) = l;
                 }
@@ -516,9 +522,9 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fin[(16 * mt + 4 * q + r) * FFN_FLD + wave * 64 + 16 * t + i] = yacc[mt][t][r];
+            for (int r = 0; r < 4; ++r) fin[(16 * mt + 4 * q + r) * FFN_FLD + wave * CW + 16 * t + i] = yacc[mt][t][r];
     __syncthreads();
     {
         const int l16 = tid & 15;
@@ -529,8 +535,9 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
             if (P.lno_g) { gv[j] = ldg4(P.lno_g + 4 * (l16 + 16 * j)); bv[j] = ldg4(P.lno_b + 4 * (l16 + 16 * j)); }
         }
 #pragma unroll
-        for (int ps = 0; ps < MT; ++ps) {
-            const int row = (tid >> 4) + 16 * ps, m = bm0 + row;
+        for (int ps = 0; ps < (R + 4 * NW - 1) / (4 * NW); ++ps) {
+            const int row = (tid >> 4) + 4 * NW * ps, m = bm0 + row;
+            if (row >= R) continue;
             const long long go = (long long)min(m, P.M - 1) * RNNT_D;
             float4 v[4];
 #pragma unroll
@@ -595,28 +602,29 @@ __global__ __launch_bounds__(256) void ffn_as(FfnP P) {
         static_assert(R * FFN_FLD * 4 <= FFN_TIMG, "the tail image must start behind the result rows");
         const unsigned char* Top = ffn_smem + FFN_TIMG;
         float* estage2 = reinterpret_cast<float*>(ffn_smem + FFN_TIMG + IMG) + wave * (16 * AS_SLD);
+        // (matrix, CW-column group) pairs of this wave
         __syncthreads();                                            // tail image complete
         // (matrix, 64-column group) pairs of this wave, one after the other; the next pair's first unit is in flight across the epilogue
         int gi = 0, grp = wave;
-        while (gi < P.n_tail && grp * 64 >= P.tg[gi].N) { ++gi; grp = wave; }
-        if (gi < P.n_tail) bload(b0[0], P.twp[gi], 8, grp, 0);
+        while (gi < P.n_tail && grp * CW >= P.tg[gi].N) { ++gi; grp = wave; }
+        if (gi < P.n_tail) bload(b0[0], P.twp[gi], 8, grp * NTW, 0);
         while (gi < P.n_tail) {
-            int ngi = gi, ngrp = grp + 4;
-            while (ngi < P.n_tail && ngrp * 64 >= P.tg[ngi].N) { ++ngi; ngrp = wave; }
+            int ngi = gi, ngrp = grp + NW;
+            while (ngi < P.n_tail && ngrp * CW >= P.tg[ngi].N) { ++ngi; ngrp = wave; }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NTW; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
             const uint4* Wp = P.twp[gi];
 #pragma unroll
             for (int ks = 0; ks < 8; ks += 2) {
-                bload(b0[1], Wp, 8, grp, ks + 1);
+                bload(b0[1], Wp, 8, grp * NTW, ks + 1);
                 mma(hacc, b0[0], ks, Top);
-                if (ks + 2 < 8) bload(b0[0], Wp, 8, grp, ks + 2);
-                else if (ngi < P.n_tail) bload(b0[0], P.twp[ngi], 8, ngrp, 0);
+                if (ks + 2 < 8) bload(b0[0], Wp, 8, grp * NTW, ks + 2);
+                else if (ngi < P.n_tail) bload(b0[0], P.twp[ngi], 8, ngrp * NTW, 0);
                 mma(hacc, b0[1], ks + 1, Top);
             }
-            as_epilogue<MT>(P.tg[gi], hacc, bm0, grp * 64, estage2, lane);
+            as_epilogue<MT, NTW>(P.tg[gi], hacc, bm0, grp * CW, estage2, lane);
             gi = ngi; grp = ngrp;
         }
     }

@@ -188,20 +188,24 @@ static void problem_ffn(int M, bool lno) {
 #define FFN_MT 3
 #endif
     constexpr int MT = FFN_MT;
-    const size_t lds = (size_t)2 * 2 * 16 * MT * 512 + 4 * 16 * AS_SLD * 4;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_as<RNNT_NUM_BF16X3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifndef FFN_NW
+#define FFN_NW 4
+#endif
+    constexpr int NW = FFN_NW;
+    const size_t lds = (size_t)2 * 2 * 16 * MT * 512 + NW * 16 * AS_SLD * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_as<RNNT_NUM_BF16X3, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((M + 16 * MT - 1) / (16 * MT));
     std::vector<float> first(hX.size()), out(hX.size());
     int nondet = 0;
     for (int r = 0; r < 3; ++r) {
-        hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT>), grid, dim3(256), lds, 0, P);
+        hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT, NW>), grid, dim3(64 * NW), lds, 0, P);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(r ? out.data() : first.data(), Y, hX.size() * 4, hipMemcpyDeviceToHost));
         if (r && memcmp(out.data(), first.data(), hX.size() * 4)) ++nondet;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT>), grid, dim3(256), lds, 0, P);
+    for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT, NW>), grid, dim3(64 * NW), lds, 0, P);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -228,6 +232,7 @@ static void problem_ffn(int M, bool lno) {
         }
         for (int n = 0; n < 256; ++n) worst = std::max(worst, fabs(y[n] - first[(size_t)m * 256 + n]));
     }
+    { unsigned long long cs = 0; for (size_t e = 0; e < first.size(); ++e) { unsigned u; memcpy(&u, &first[e], 4); cs += u; } printf("             output checksum %016llx (NW = %d)\n", cs, NW); }
     printf("  ffn_as<%d>  %8.1f us  %7.1f TFLOP/s (algorithmic, both contractions)  max |err| vs double reference %.3e  runs differing: %d/2\n",
            MT, us, 4.0 * M * 256 * 1024 / us / 1e6, worst, nondet);
 }
