@@ -61,7 +61,7 @@ def site_kernel(site, mode):
                     "ffn": "ffn_as (LayerNorm + w_1 + SiLU + w_2 + half-step residual [+ norm_final], hidden activation in LDS, M = B*F)",
                     "qkv": "gemm_as x3 (LayerNorm once, linear_q/k/v from one staged operand image, K/V rows into the cache)",
                     "pw1": "gemm_as (LayerNorm + pointwise_conv1 + GLU)"}[site]
-        return {"conv1": "conv1_relu_rows", "conv2": f"{gk} (conv2 implicit GEMM, all equal-length chunks in one launch)", "embed": f"{gk} (embed Linear)",
+        return {"conv1": "conv1_relu_rows", "conv2": ("gemm_bw (conv2 implicit GEMM of all equal-length chunks: 128x256 tiles, weights streamed from L2 in fragment order)" if bf else f"{gk} (conv2 implicit GEMM)"), "embed": f"{gk} (embed Linear)",
                 "ffn1": f"{gk} (ffn w_1 + LayerNorm prologue + SiLU, M = B*F)", "ffn2": f"{gk} (ffn w_2 + half-step residual, M = B*F)",
                 "qkv": f"{gk} x3 (linear_q/k/v + LayerNorm prologue, K/V rows into the cache)", "attn_out": f"{gk} (linear_out + residual)",
                 "pw1": f"{gk} (pointwise_conv1 + LayerNorm prologue + GLU)", "pw2": f"{gk} (pointwise_conv2 + residual)",
@@ -172,7 +172,7 @@ def pmc_traffic(kernel_prefixes):
     return None
 
 
-PMC_PREFIX = {"block_front": ["void block_front"], "block_back": ["void block_back"], "conv2": ["void gemm_bf<2, false, 4, 4", "void gemm_ns<2, 2, 32"],
+PMC_PREFIX = {"block_front": ["void block_front"], "block_back": ["void block_back"], "conv2": ["void gemm_bw", "void gemm_bf<2, false, 4, 4", "void gemm_ns<2, 2, 32"],
               "attn": ["rel_attention_lm_mfma", "rel_attention_stream_tab"], "ffn2": ["void gemm_ns_tab<1, 1, 64"], "dwconv": ["dwconv_lm", "dwconv_bn_silu_tab"],
               "ffn": ["void ffn_as"], "ffn_qkv": ["void ffn_as"], "conv1": ["conv1_relu_rows"]}
 
