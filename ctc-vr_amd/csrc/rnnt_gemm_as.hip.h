@@ -638,36 +638,37 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 // the MFMAs), reads every A element from HBM once (N is not split) and gives each wave 96 MFMAs per 8 KiB of weights, which
 // is what the per-CU L2 fetch rate (~45 GB/s) can feed.  Same products and k order as gemm_bf.
 // ------------------------------------------------------------------------------------------------
-template <int NUM>
-__global__ __launch_bounds__(256) void gemm_bw(GemmP p, const uint4* __restrict__ wp) {
+// NW waves (4 or 8): every wave owns 256 / NW output columns of all 128 rows; 8 = two waves per SIMD.
+template <int NUM, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restrict__ wp) {
     using C = FuseCfg<NUM>;
     constexpr bool F16 = C::F16, LO = C::PLANES == 2;
-    constexpr int U = C::PLANES, MT = 8;
+    constexpr int U = C::PLANES, MT = 8, NTW = 16 / NW, NT = 64 * NW, AJ = 512 / NT;   // AJ: 8-float A chunks per thread and k-step
     __shared__ uint4 Ah[2][512];
     __shared__ uint4 Al[LO ? 2 : 1][LO ? 512 : 1];
-    __shared__ __attribute__((aligned(16))) float estage_all[4 * 16 * AS_SLD];
+    __shared__ __attribute__((aligned(16))) float estage_all[NW * 16 * AS_SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int bm0 = blockIdx.x * 128;
     if (bm0 >= p.M) return;
     const int srow = tid >> 2, sc = tid & 3;
-    const float* ag[2];
+    const float* ag[AJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) ag[j] = p.A + a_row_off(p, min(bm0 + srow + 64 * j, p.M - 1));
+    for (int j = 0; j < AJ; ++j) ag[j] = p.A + a_row_off(p, min(bm0 + srow + (NT / 4) * j, p.M - 1));
     const bool aplain = p.a_plain != 0;
     const int KT = p.K >> 5;
     // the A stream comes from HBM (1.09 GB for conv2): its loads run FOUR k-steps ahead of the MFMAs in a register ring
-    float4 ra[4][2][2];
-    auto gload = [&](float4 (&r)[2][2], int blk) {
+    float4 ra[4][AJ][2];
+    auto gload = [&](float4 (&r)[AJ][2], int blk) {
         const int kk = blk * 32 + 8 * sc;
         const long long ko = aplain ? (long long)kk : a_k_off(p, kk);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { r[j][0] = ldg4_nt(ag[j] + ko); r[j][1] = ldg4_nt(ag[j] + ko + 4); }   // streamed once: keep the weights in L2
+        for (int j = 0; j < AJ; ++j) { r[j][0] = ldg4_nt(ag[j] + ko); r[j][1] = ldg4_nt(ag[j] + ko + 4); }   // streamed once: keep the weights in L2
     };
-    auto lstore = [&](int buf, const float4 (&r)[2][2]) {
+    auto lstore = [&](int buf, const float4 (&r)[AJ][2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rr = srow + 64 * j;
+        for (int j = 0; j < AJ; ++j) {
+            const int rr = srow + (NT / 4) * j;
             uint4 h, l;
             split8_16<F16, LO>(r[j][0], r[j][1], h, l);
             const int slot = rr * 4 + (sc ^ bf_swz(rr));
@@ -675,27 +676,27 @@ __global__ __launch_bounds__(256) void gemm_bw(GemmP p, const uint4* __restrict_
             if constexpr (LO) Al[buf][slot] = l;
         }
     };
-    auto bload = [&](uint4 (&b)[4 * U], int kt) {
+    auto bload = [&](uint4 (&b)[NTW * U], int kt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 typedef unsigned u32x4g_ __attribute__((ext_vector_type(4)));
-                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(wp + ((long long)((wave * 4 + t) * KT + kt) * U + u) * 64 + lane);
+                const u32x4g_ v = *(const RNNT_GAS u32x4g_*)(wp + ((long long)((wave * NTW + t) * KT + kt) * U + u) * 64 + lane);
                 b[t * U + u] = make_uint4(v[0], v[1], v[2], v[3]);
 #else
-                b[t * U + u] = wp[((long long)((wave * 4 + t) * KT + kt) * U + u) * 64 + lane];
+                b[t * U + u] = wp[((long long)((wave * NTW + t) * KT + kt) * U + u) * 64 + lane];
 #endif
             }
     };
-    f32x4_ acc[MT][4];
+    f32x4_ acc[MT][NTW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
     const int fsw = q ^ bf_swz(i);
-    auto mma = [&](int buf, const uint4 (&b)[4 * U]) {
+    auto mma = [&](int buf, const uint4 (&b)[NTW * U]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int slot = (16 * mt + i) * 4 + fsw;
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256) void gemm_bw(GemmP p, const uint4* __restrict_
             uint4 al = ah;
             if constexpr (LO) al = Al[buf][slot];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < NTW; ++t) {
                 if constexpr (LO) {
                     acc[mt][t] = mfma16_<F16>(al, b[t * U], acc[mt][t]);
                     acc[mt][t] = mfma16_<F16>(ah, b[t * U + 1], acc[mt][t]);
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256) void gemm_bw(GemmP p, const uint4* __restrict_
             }
         }
     };
-    uint4 b0[4 * U], b1[4 * U];
+    uint4 b0[NTW * U], b1[NTW * U];
 #pragma unroll
     for (int k = 0; k < 4; ++k) gload(ra[k], k);                     // KT >= 4 and KT % 4 == 0 (host check)
     bload(b0, 0);
@@ -731,5 +732,5 @@ __global__ __launch_bounds__(256) void gemm_bw(GemmP p, const uint4* __restrict_
             __syncthreads();
         }
     }
-    as_epilogue<MT>(p, acc, bm0, wave * 64, estage_all + wave * (16 * AS_SLD), lane);
+    as_epilogue<MT, NTW>(p, acc, bm0, wave * 16 * NTW, estage_all + wave * (16 * AS_SLD), lane);
 }

@@ -250,22 +250,24 @@ int main() {
         auto r48 = run<4, 8>("<4,8>", p, 5);
         auto r28 = run<2, 8>("<2,8>", p, 5);
         auto r44 = run<4, 4>("<4,4>", p, 5);
-        {
+        auto run_bw = [&](auto kern, int threads, const char* nm) {
             GemmBatch gb = desc(p);
             dim3 grid((p.M + 127) / 128);
             std::vector<float> o(r22.size());
             CK(hipMemset(p.C, 0xff, o.size() * 4));
-            hipLaunchKernelGGL((gemm_bw<RNNT_NUM_BF16X3>), grid, dim3(256), 0, 0, gb.g[0], p.Wp);
+            hipLaunchKernelGGL(kern, grid, dim3(threads), 0, 0, gb.g[0], p.Wp);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(o.data(), p.C, o.size() * 4, hipMemcpyDeviceToHost));
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             CK(hipEventRecord(e0, 0));
-            for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((gemm_bw<RNNT_NUM_BF16X3>), grid, dim3(256), 0, 0, gb.g[0], p.Wp);
+            for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, grid, dim3(threads), 0, 0, gb.g[0], p.Wp);
             CK(hipEventRecord(e1, 0));
             CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("  gemm_bw     %8.1f us  %7.1f TFLOP/s   == <2,2>: %d\n", ms * 1e3 / 5, 2.0 * p.M * p.N * p.K / (ms * 1e3 / 5) / 1e6, (int)!memcmp(o.data(), r22.data(), o.size() * 4));
-        }
+            printf("  %-11s %8.1f us  %7.1f TFLOP/s   == <2,2>: %d\n", nm, ms * 1e3 / 5, 2.0 * p.M * p.N * p.K / (ms * 1e3 / 5) / 1e6, (int)!memcmp(o.data(), r22.data(), o.size() * 4));
+        };
+        run_bw(gemm_bw<RNNT_NUM_BF16X3, 4>, 256, "gemm_bw<4>");
+        run_bw(gemm_bw<RNNT_NUM_BF16X3, 8>, 512, "gemm_bw<8>");
         printf("  <4,8> == <2,2>: %d, <2,8> == <2,2>: %d\n", (int)!memcmp(r48.data(), r22.data(), r22.size() * 4), (int)!memcmp(r28.data(), r22.data(), r22.size() * 4));
         return 0;
     }
