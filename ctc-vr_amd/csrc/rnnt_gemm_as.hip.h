@@ -35,6 +35,7 @@ struct AsBatch {
 template <int MT, int NTW = 4>
 __device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[MT][NTW], int m0, int n0, float* stage, int lane) {
     constexpr int LPR = 4 * NTW, RPP = 64 / LPR;                   // lanes per row (float4 each), rows per read-back pass
+    constexpr int SLD = 16 * NTW + 4;                              // staging row stride in floats (68 for the 64-column form)
     const int i = lane & 15, q = lane >> 4;
     const int epi = p.epi;
     const int c4 = (lane % LPR) * 4, n = n0 + c4;
@@ -45,7 +46,7 @@ __device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(4 * q + r) * AS_SLD + 16 * t + i] = acc[mt][t][r];
+            for (int r = 0; r < 4; ++r) stage[(4 * q + r) * SLD + 16 * t + i] = acc[mt][t][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -53,7 +54,7 @@ __device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[
         for (int j = 0; j < 16 / RPP; ++j) {
             const int rr = lane / LPR + RPP * j;
             const int m = m0 + 16 * mt + rr;
-            float4 v = *reinterpret_cast<const float4*>(&stage[rr * AS_SLD + c4]);
+            float4 v = *reinterpret_cast<const float4*>(&stage[rr * SLD + c4]);
             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
             if (m >= p.M) continue;
             const long long crow = c_row_off(p, m);
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
     constexpr int U = C::PLANES, MT = 8, NTW = 16 / NW, NT = 64 * NW, AJ = 512 / NT;   // AJ: 8-float A chunks per thread and k-step
     __shared__ uint4 Ah[2][512];
     __shared__ uint4 Al[LO ? 2 : 1][LO ? 512 : 1];
-    __shared__ __attribute__((aligned(16))) float estage_all[NW * 16 * AS_SLD];
+    __shared__ __attribute__((aligned(16))) float estage_all[NW * 16 * (16 * NTW + 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int bm0 = blockIdx.x * 128;
@@ -732,5 +733,5 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
             __syncthreads();
         }
     }
-    as_epilogue<MT, NTW>(p, acc, bm0, wave * 16 * NTW, estage_all + wave * (16 * AS_SLD), lane);
+    as_epilogue<MT, NTW>(p, acc, bm0, wave * 16 * NTW, estage_all + wave * (16 * (16 * NTW + 4)), lane);
 }
