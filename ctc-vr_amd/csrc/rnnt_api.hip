@@ -54,6 +54,10 @@ struct rnnt_ctx {
     size_t fuse_w_vecs = 0;
     LayerDev* layers_dev = nullptr;
     const uint4* conv2_wp = nullptr;          // fragment-major packed conv2 weights of the current numerics mode (gemm_bw)
+    unsigned char* joint_wfrag = nullptr;     // joint.ffn_out as the LDS-DMA ring's stage stream (pack_joint_w), split modes and bf16
+    size_t joint_wfrag_bytes = 0;
+    int* joint_counter = nullptr;             // joint_lattice_rows' dynamic row-tile queue (zeroed before every launch)
+    bool joint_attr[2] = {false, false};      // dynamic-LDS attribute set for the current mode's (logits, log-softmax) kernels
     std::vector<LayerDev> layers_host;        // host copy (packed-weight pointers for gemm_as / ffn_as launches)
     int use_as = 1;                            // RNNT_AS=0: LDS-tiled gemm_bf for every layer contraction of the layer-major schedule
     int use_fused = 1;                         // RNNT_FUSED=0: the unfused wavefront (11 launches per stage)

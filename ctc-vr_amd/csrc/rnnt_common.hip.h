@@ -8,7 +8,8 @@
 //   rnnt_gemm      gemm16 (16-row tiles, split-K, LSTM-cell / fused-argmax epilogues), gemm_ns / gemm_ns_tab (LDS-tiled
 //                  grouped GEMM, LayerNorm prologue, XCD-aware mapping) -- exact f32 (v_mfma_f32_16x16x4_f32)
 //   rnnt_gemm_bf   gemm_bf / gemm_bf_tab: the same GEMM contract on v_mfma_f32_16x16x32_{bf16,f16} with split operands
-//                  (bf16x3 / f16x3: hi*hi + hi*lo + lo*hi, f32 accumulate; bf16: hi*hi), joint_lattice_fused
+//                  (bf16x3 / f16x3: hi*hi + hi*lo + lo*hi, f32 accumulate; bf16: hi*hi)
+//   rnnt_joint     joint_lattice_rows: the T x U joint lattice (tanh-add, projection, log-softmax) as one persistent kernel, pack_joint_w
 //   rnnt_encoder   conv1_relu, layer_norm, rel_attention (LDS tiles, online softmax), rel_attention_stream (<= 4 queries,
 //                  direct row streaming), dwconv_bn_silu, conv_ring_init
 //   rnnt_decode    greedy_decide (launched path), greedy_stream (resident decoder), greedy_flow (cooperative experiment),

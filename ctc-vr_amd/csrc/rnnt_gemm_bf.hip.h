@@ -298,210 +298,3 @@ __global__ __launch_bounds__(256) void gemm_bf_tab(const GemmP* __restrict__ tab
     const GemmP p = tab[g];
     gemm_bf_body<NSPLIT, F16, MT, NT, false>(p, n, m);
 }
-
-// ------------------------------------------------------------------------------------------------
-// joint_lattice<NSPLIT,F16,LSM>: TransducerJoint.forward in lattice form (model/component/joint.py:48-69; training lattice
-// online_rnnt_model.py:243, beam log_softmax :446-447) as ONE kernel:
-//     out[b,t,u,:] = (log_softmax?)( tanh(e[b,t,:] + p[b,u,:]) * W_out^T + b_out )
-// e = joint.enc_ffn(enc) [B*T][256] and p = joint.pred_ffn(pred) [B*U][256] come from two small GEMMs.  The lattice is
-// output-bound (1648 bytes per cell against 211 kFLOP: SURVEY.md §8d); a workgroup owns 128 lattice rows x the WHOLE
-// vocabulary (26 column tiles of 16 for V = 412), so the row maximum and the log-sum-exp are taken on the accumulators and
-// the normalised row is written once -- no second pass over the 735 MB lattice.
-// 8 waves as 4 (rows) x 2 (column halves), wave tile 32 x 208 (2 x 13 MFMA tiles, 104 accumulator registers); K = 256 in 8
-// blocks of 32 through two LDS buffers; the A block is FORMED while it is staged (tanh of the broadcast sum, split into
-// planes): there is no [B,T,U,256] intermediate anywhere.  The two column halves of a row exchange (max, sum) through LDS.
-// Rows go out with non-temporal stores (written once, larger than the Infinity Cache).
-// ------------------------------------------------------------------------------------------------
-// tanh for the lattice's A operand: 1 - 2 / (exp(2x) + 1) on the hardware exp / rcp (abs error ~2e-7 on |x| < 10, saturates cleanly);
-// the libm tanhf costs as many VALU cycles per workgroup as the whole MFMA work of the tile (32 K evaluations)
-__device__ __forceinline__ float jl_tanh(float x) {
-    const float e = __expf(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
-    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
-}
-#define JL_BM 128
-#define JL_NT 13                 // column tiles per wave: 2 * 13 * 16 = 416 columns >= vocab
-struct JointLP {
-    const float* e;              // [B*T][256]
-    const float* p;              // [B*U][256]
-    const unsigned short* wh;    // W_out planes [V][256]
-    const unsigned short* wl;
-    const float* bias;           // [V]
-    float* out;                  // [M][V]
-    long long M;                 // B*T*U
-    int T, U, V;
-};
-template <int NSPLIT, bool F16, bool LSM>
-__global__ __launch_bounds__(512) void joint_lattice(JointLP P) {
-    constexpr bool LO = NSPLIT == 2;
-    constexpr int BN = 2 * JL_NT * 16;                         // 416
-    constexpr int ACH = JL_BM * 4, WCH = BN * 4;
-    extern __shared__ uint4 jl_smem[];
-    uint4* Ah = jl_smem;                                       // [2][ACH]
-    uint4* Al = Ah + 2 * ACH;                                  // [2][ACH]  (unused when !LO)
-    uint4* Wh = Al + (LO ? 2 * ACH : 0);                       // [2][WCH]
-    uint4* Wl = Wh + 2 * WCH;
-    float* rstat = reinterpret_cast<float*>(Wl + (LO ? 2 * WCH : 0));   // [2 halves][128 rows][2] (max, sum)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 15, kq = lane >> 4;
-    const long long m0 = (long long)blockIdx.x * JL_BM;
-    // staging: A chunk (row = tid >> 2, chunk = tid & 3); W chunks e = tid + 512 j
-    const int srow = tid >> 2, sc = tid & 3;
-    const long long am = min(m0 + srow, P.M - 1);
-    const long long bt = am / P.U;                             // (b, t) row of e
-    const int u = (int)(am - bt * P.U);
-    const long long bb = bt / P.T;
-    const float* eg = P.e + bt * RNNT_D;
-    const float* pg = P.p + (bb * P.U + u) * RNNT_D;
-    constexpr int WJ = (WCH + 511) / 512;
-    const unsigned short* whg[WJ];
-    const unsigned short* wlg[WJ];
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        const int r = min((tid + 512 * j) >> 2, P.V - 1);
-        whg[j] = P.wh + (long long)r * RNNT_D;
-        wlg[j] = P.wl + (long long)r * RNNT_D;
-    }
-    float4 re[2], rp[2];
-    uint4 rwh[WJ], rwl[LO ? WJ : 1];
-    auto gload = [&](int blk) {
-        const int kk = blk * 32 + 8 * sc;
-        re[0] = ldg4(eg + kk); re[1] = ldg4(eg + kk + 4);
-        rp[0] = ldg4(pg + kk); rp[1] = ldg4(pg + kk + 4);
-#pragma unroll
-        for (int j = 0; j < WJ; ++j)
-            if (tid + 512 * j < WCH) {
-                rwh[j] = ldg_u4(whg[j] + kk);
-                if constexpr (LO) rwl[j] = ldg_u4(wlg[j] + kk);
-            }
-    };
-    auto lstore = [&](int buf) {
-        float4 v0, v1;
-        v0.x = jl_tanh(re[0].x + rp[0].x); v0.y = jl_tanh(re[0].y + rp[0].y); v0.z = jl_tanh(re[0].z + rp[0].z); v0.w = jl_tanh(re[0].w + rp[0].w);
-        v1.x = jl_tanh(re[1].x + rp[1].x); v1.y = jl_tanh(re[1].y + rp[1].y); v1.z = jl_tanh(re[1].z + rp[1].z); v1.w = jl_tanh(re[1].w + rp[1].w);
-        uint4 h, l;
-        split8_16<F16, LO>(v0, v1, h, l);
-        const int slot = srow * 4 + (sc ^ bf_swz(srow));
-        Ah[buf * ACH + slot] = h;
-        if constexpr (LO) Al[buf * ACH + slot] = l;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int e2 = tid + 512 * j;
-            if (e2 < WCH) {
-                const int r = e2 >> 2;
-                const int sl = r * 4 + (sc ^ bf_swz(r));
-                Wh[buf * WCH + sl] = rwh[j];
-                if constexpr (LO) Wl[buf * WCH + sl] = rwl[j];
-            }
-        }
-    };
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * (JL_NT * 16);
-    f32x4_ acc[2][JL_NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int t = 0; t < JL_NT; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    const int fsw = kq ^ bf_swz(i);
-    for (int blk = 0; blk < 8; ++blk) {
-        const int buf = blk & 1;
-        if (blk + 1 < 8) gload(blk + 1);
-        uint4 ah[2], al[LO ? 2 : 1];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int slot = (wm + 16 * mt + i) * 4 + fsw;
-            ah[mt] = Ah[buf * ACH + slot];
-            if constexpr (LO) al[mt] = Al[buf * ACH + slot];
-        }
-#pragma unroll
-        for (int t = 0; t < JL_NT; ++t) {
-            const int slot = (wn + 16 * t + i) * 4 + fsw;
-            const uint4 bh = Wh[buf * WCH + slot];
-            uint4 bl = bh;
-            if constexpr (LO) bl = Wl[buf * WCH + slot];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                if constexpr (LO) {
-                    acc[mt][t] = mfma16_<F16>(al[mt], bh, acc[mt][t]);
-                    acc[mt][t] = mfma16_<F16>(ah[mt], bl, acc[mt][t]);
-                }
-                acc[mt][t] = mfma16_<F16>(ah[mt], bh, acc[mt][t]);
-            }
-        }
-        if (blk + 1 < 8) lstore(buf ^ 1);
-        __syncthreads();
-    }
-    // ---- epilogue: bias, (log-softmax over the whole vocabulary row), store --------------------------------------------------
-    float bias[JL_NT];
-    bool nin[JL_NT];
-#pragma unroll
-    for (int t = 0; t < JL_NT; ++t) {
-        const int n = wn + 16 * t + i;
-        nin[t] = n < P.V;
-        bias[t] = nin[t] ? ldg1(P.bias + n) : 0.f;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int t = 0; t < JL_NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][t][r] += bias[t];
-    float lse[2][4];
-    if constexpr (LSM) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int t = 0; t < JL_NT; ++t) mx = fmaxf(mx, nin[t] ? acc[mt][t][r] : -INFINITY);
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-                float sm = 0.f;
-#pragma unroll
-                for (int t = 0; t < JL_NT; ++t) sm += nin[t] ? __expf(acc[mt][t][r] - mx) : 0.f;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
-                if (i == 0) {
-                    const int row = wm + 16 * mt + 4 * kq + r;
-                    rstat[((wave & 1) * JL_BM + row) * 2] = mx;
-                    rstat[((wave & 1) * JL_BM + row) * 2 + 1] = sm;
-                }
-            }
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm + 16 * mt + 4 * kq + r;
-                const float m0_ = rstat[row * 2], s0 = rstat[row * 2 + 1], m1 = rstat[(JL_BM + row) * 2], s1 = rstat[(JL_BM + row) * 2 + 1];
-                const float mx = fmaxf(m0_, m1);
-                lse[mt][r] = mx + __logf(s0 * __expf(m0_ - mx) + s1 * __expf(m1 - mx));   // log_softmax = x - logsumexp(x)
-            }
-    }
-    // The rows leave through LDS so that every store instruction writes 16 bytes per lane and 1 KiB contiguous per wave (a row of
-    // 412 floats is 103 float4, rows are 16-byte aligned): straight from the accumulators a lane owns one column of four rows, i.e.
-    // 4-byte stores in 64-byte pieces, and the epilogue was store-issue bound (~50 us per workgroup against ~4 us of MFMA).
-    // The wave's 16 x 208 sub-tile of row tile mt goes to its own 13 KiB of the (now free) operand buffers.
-    float* stage = reinterpret_cast<float*>(jl_smem) + wave * (16 * 208);
-    const int ncol = min(208, P.V - wn);                       // valid columns of this wave's half (a multiple of 4 for V % 4 == 0)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        __syncthreads();                                       // operand buffers / previous round fully consumed
-#pragma unroll
-        for (int t = 0; t < JL_NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[mt][t][r];
-                if constexpr (LSM) v -= lse[mt][r];
-                stage[(4 * kq + r) * 208 + 16 * t + i] = v;
-            }
-        __syncthreads();
-        for (int e = lane; e < 16 * 52; e += 64) {
-            const int rr = e / 52, c4 = (e - rr * 52) * 4;
-            const long long m = m0 + wm + 16 * mt + rr;
-            if (m < P.M && c4 < ncol) stg4_nt(P.out + m * P.V + wn + c4, *reinterpret_cast<const float4*>(&stage[rr * 208 + c4]));
-        }
-    }
-}

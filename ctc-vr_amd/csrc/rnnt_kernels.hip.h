@@ -3,6 +3,7 @@
 #include "rnnt_common.hip.h"
 #include "rnnt_gemm.hip.h"
 #include "rnnt_gemm_bf.hip.h"
+#include "rnnt_joint.hip.h"
 #include "rnnt_encoder.hip.h"
 #include "rnnt_encoder_lm.hip.h"
 #include "rnnt_decode.hip.h"

@@ -93,6 +93,36 @@ def test_predictor_and_joint_step_api(seed, models, numerics):
         assert np.array_equal(out.argmax(-1).cpu().numpy(), g[key].argmax(-1))
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 37, 11), (5, 64, 28), (2, 129, 3)])
+def test_joint_lattice_shapes(shape, models, numerics, np_state_dict):
+    """rnnt_joint in lattice form (joint.py:48-69, online_rnnt_model.py:243,446-447) on row counts that are not multiples of the
+    kernel's 64-row tile, through the persistent row-tile queue: logits and log-softmax within LOGIT_TOL of the oracle, same
+    argmax, and two calls bit-identical (the queue hands tiles to workgroups in a different order every launch)."""
+    from oracle import rnnt_oracle as O
+    B, Tn, U = shape
+    m = models(0, 16)
+    eng, dev = m._engine, m.device
+    sd = O.to_torch_sd(np_state_dict(0))
+    g = torch.Generator().manual_seed(100 * B + Tn)
+    enc = torch.randn(B, Tn, 256, generator=g)
+    prd = torch.randn(B, U, 256, generator=g) * 0.5
+    want = O.joint(sd, enc, prd)                                  # [B, T, U, V] logits
+    want_lp = torch.log_softmax(want, dim=-1)
+    s = torch.cuda.current_stream().cuda_stream
+    enc_d, prd_d = enc.to(dev), prd.to(dev)
+    for mode, ref in ((0, want), (1, want_lp)):
+        out = torch.full((B, Tn, U, T.VOCAB), float("nan"), device=dev)
+        eng.joint(enc_d.data_ptr(), prd_d.data_ptr(), B, Tn, U, mode, out.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        assert maxdiff(out, ref.numpy()) < LOGIT_TOL
+        assert np.array_equal(out.argmax(-1).cpu().numpy(), ref.argmax(-1).numpy())
+        again = torch.empty_like(out)
+        eng.joint(enc_d.data_ptr(), prd_d.data_ptr(), B, Tn, U, mode, again.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(out, again)
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_forward_chunk_traces(seed, models, numerics):
     """Three consecutive 16-frame chunks: encoder output and both caches in the reference's layouts,
