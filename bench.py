@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 # launch-site tags of rnnt_profile_begin (include/rnnt_hip.h)
 TAGS = {"conv1": 1, "conv2": 2, "embed": 3, "ffn1": 4, "ffn2": 5, "qkv": 6, "attn": 7, "attn_out": 8, "pw1": 9,
         "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33, "out_pw1": 34}
+TAG_JOINT_OUT = 23   # the lattice kernel's launch site (host_launch.hip.inc)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak of the operand type
 MFMA_PER_ALG = {"fp32": 1, "bf16x3": 3, "f16x3": 3, "bf16": 1}                      # MFMA products issued per algorithmic product
 PEAK_HBM_GBS = 8000.0
@@ -212,6 +213,7 @@ def main():
                          "runs beside the other's encoder (every step is still one whole batch; the single-batch latency is reported beside it)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (beam, full context, joint lattice, C64, per-chunk API)")
+    ap.add_argument("--legs", default="all", help="secondary legs to run: all, none, or a comma list of chunkapi,c64,beam4,full,joint (tools/profile_bench.sh profiles the joint lattice with --legs joint)")
     ap.add_argument("--blank-bias", type=float, default=12.0,
                     help="bias on the blank logit of the seeded weights: sets the greedy symbol rate (SURVEY.md §8d asks for 0.3-1 symbols per "
                          "encoder frame; 12.0 gives 0.75, the fixtures' 11.0 gives 1.40, 14.0 gives 0.17)")
@@ -477,125 +479,151 @@ def main():
                            "weight_bytes_streamed_per_symbol": 0 if multi else 4 * (1024 * 256 + 256 * 256 + 412 * 256),
                            "exchange_bytes_per_symbol_per_part": 8 * (320 + 8) if multi else 0,
                            "bound": "dependent chain of the slowest stream (latency), not bandwidth"}
-    if args.no_legs:
+    ALL_LEGS = ["chunkapi", "c64", "beam4", "full", "joint"]
+    want = [] if (args.no_legs or args.legs == "none") else (ALL_LEGS if args.legs == "all" else [w for w in args.legs.split(",") if w])
+    for w in want:
+        if w not in ALL_LEGS:
+            raise SystemExit(f"--legs: unknown leg {w!r} (choose from {ALL_LEGS})")
+    if not want:
         print(json.dumps(out))
         return
 
     # ---- per-chunk API (the reference's actual call pattern): throughput + per-chunk RTF percentiles (online_rnnt_delay.py:55-59,99-131) ----
-    sb.decode_script(x, args.chunk, per_chunk_decode=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    toks_pc = sb.decode_script(x, args.chunk, per_chunk_decode=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    rtfs = []
-    sb.reset()
-    for (a, b) in plan:
-        c = x[:, a:b, :].contiguous()
+    if "chunkapi" in want:
+        sb.decode_script(x, args.chunk, per_chunk_decode=True)
         torch.cuda.synchronize()
-        t1 = time.time()
-        sb.process_chunk(c, decode=True)
-        sb.engine.token_counts(cs)                      # tokens of the chunk reach the host (synchronises, like the reference's .item())
-        rtfs.append((time.time() - t1) / ((b - a) * 0.01))
-    r = np.asarray(rtfs)
-    out["per_chunk_api"] = {"value": round(B * args.frames / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tokens_equal_whole_utterance_call": toks_pc == toks,
-                            "rtf_per_chunk": {"mean": float(r.mean()), "p50": float(np.percentile(r, 50)), "p80": float(np.percentile(r, 80)), "p90": float(np.percentile(r, 90)),
-                                              "p95": float(np.percentile(r, 95)), "max": float(r.max()), "chunks": int(r.size),
-                                              "definition": f"wall time of one chunk call for all {B} streams / chunk audio duration (online_rnnt_delay.py:55-59)"},
-                            "note": "tokens copied to the host after every chunk (online_rnnt_decode.py loop, process_single_chunk API)"}
+        t0 = time.perf_counter()
+        toks_pc = sb.decode_script(x, args.chunk, per_chunk_decode=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rtfs = []
+        sb.reset()
+        for (a, b) in plan:
+            c = x[:, a:b, :].contiguous()
+            torch.cuda.synchronize()
+            t1 = time.time()
+            sb.process_chunk(c, decode=True)
+            sb.engine.token_counts(cs)                      # tokens of the chunk reach the host (synchronises, like the reference's .item())
+            rtfs.append((time.time() - t1) / ((b - a) * 0.01))
+        r = np.asarray(rtfs)
+        out["per_chunk_api"] = {"value": round(B * args.frames / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tokens_equal_whole_utterance_call": toks_pc == toks,
+                                "rtf_per_chunk": {"mean": float(r.mean()), "p50": float(np.percentile(r, 50)), "p80": float(np.percentile(r, 80)), "p90": float(np.percentile(r, 90)),
+                                                  "p95": float(np.percentile(r, 95)), "max": float(r.max()), "chunks": int(r.size),
+                                                  "definition": f"wall time of one chunk call for all {B} streams / chunk audio duration (online_rnnt_delay.py:55-59)"},
+                                "note": "tokens copied to the host after every chunk (online_rnnt_decode.py loop, process_single_chunk API)"}
 
     # ---- C64 chunking (SURVEY.md §8d secondary) -------------------------------------------------------------------------------------------------
     legs = {}
-    sb64 = make_sb(choice, chunk=64)
-    sb64.decode_script(x, 64, pipelined=True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(2):
-        t64 = sb64.decode_script(x, 64, pipelined=True)
-    torch.cuda.synchronize()
-    d64 = (time.perf_counter() - t0) / 2
-    legs["c64"] = {"workload": f"configs[1] with streaming_inference chunking: 64-frame chunks, batch={B}", "ms_per_step": round(d64 * 1e3, 3), "value": round(B * args.frames / d64, 1),
-                   "unit": "audio-frames/s", "dtype": choice, "symbols_per_encoder_frame": round(float(np.mean([len(t) for t in t64])) / sum(sub_len(b - a) for a, b in T.chunk_plan(args.frames, 64)), 3)}
-    del sb64
+    if "c64" in want:
+        sb64 = make_sb(choice, chunk=64)
+        sb64.decode_script(x, 64, pipelined=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(2):
+            t64 = sb64.decode_script(x, 64, pipelined=True)
+        torch.cuda.synchronize()
+        d64 = (time.perf_counter() - t0) / 2
+        legs["c64"] = {"workload": f"configs[1] with streaming_inference chunking: 64-frame chunks, batch={B}", "ms_per_step": round(d64 * 1e3, 3), "value": round(B * args.frames / d64, 1),
+                       "unit": "audio-frames/s", "dtype": choice, "symbols_per_encoder_frame": round(float(np.mean([len(t) for t in t64])) / sum(sub_len(b - a) for a, b in T.chunk_plan(args.frames, 64)), 3)}
+        del sb64
 
     # ---- configs[2]: beam 4 ------------------------------------------------------------------------------------------------------------------
-    sbb = make_sb(choice, max_beam=4, max_tokens=16)
-    sbb.beam_script(x, args.chunk, 4, pipelined=True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(2):
-        beams = sbb.beam_script(x, args.chunk, 4, pipelined=True)
-    torch.cuda.synchronize()
-    db = (time.perf_counter() - t0) / 2
-    legs["beam4"] = {"workload": f"configs[2]: batch={B} beam_search beam=4, streaming chunk={args.chunk}; one encoder call + one rnnt_beam_advance", "ms_per_step": round(db * 1e3, 2),
-                     "value": round(B * args.frames / db, 1), "unit": "audio-frames/s", "dtype": choice, "best_tokens_stream0": len(max(beams[0], key=lambda h: h.log_prob).tokens),
-                     "roofline": {"bound": "latency", "note": "per frame one beam_chain launch whose length is the longest extension chain (<= 10 evaluations x ~27 us), "
-                                  "a copy of the candidate tables, the C++ merge and a state gather; no bandwidth or MFMA roofline applies"}}
-    del sbb
+    if "beam4" in want:
+        sbb = make_sb(choice, max_beam=4, max_tokens=16)
+        sbb.beam_script(x, args.chunk, 4, pipelined=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(2):
+            beams = sbb.beam_script(x, args.chunk, 4, pipelined=True)
+        torch.cuda.synchronize()
+        db = (time.perf_counter() - t0) / 2
+        legs["beam4"] = {"workload": f"configs[2]: batch={B} beam_search beam=4, streaming chunk={args.chunk}; one encoder call + one rnnt_beam_advance", "ms_per_step": round(db * 1e3, 2),
+                         "value": round(B * args.frames / db, 1), "unit": "audio-frames/s", "dtype": choice, "best_tokens_stream0": len(max(beams[0], key=lambda h: h.log_prob).tokens),
+                         "roofline": {"bound": "latency", "note": "per frame one beam_chain launch whose length is the longest extension chain (<= 10 evaluations x ~27 us), "
+                                      "a copy of the candidate tables, the C++ merge and a state gather; no bandwidth or MFMA roofline applies"}}
+        del sbb
 
     # ---- configs[4]: full-context encoder 32 x 30 s -----------------------------------------------------------------------------------------------
-    Bf, Tn = 32, 3000
-    eng = RnntEngine(max_streams=Bf, max_chunk_frames=Tn, max_cache_frames=760, max_enc_frames=8, vocab_size=T.VOCAB, blank_id=T.BLANK, device=local_rank)
-    eng.load_state_dict(sd_np, numerics=choice)
-    xf = torch.from_numpy(T.synth_fbank(Bf, Tn, seed=1234)).to(dev).contiguous()
-    tq = sub_len(Tn)
-    of = torch.empty(Bf, tq, 256, device=dev)
-    lens = np.full(Bf, Tn, np.int32)
-    eng.encoder_full(xf.data_ptr(), lens, Bf, Tn, of.data_ptr(), cs)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(2):
+    if "full" in want:
+        Bf, Tn = 32, 3000
+        eng = RnntEngine(max_streams=Bf, max_chunk_frames=Tn, max_cache_frames=760, max_enc_frames=8, vocab_size=T.VOCAB, blank_id=T.BLANK, device=local_rank)
+        eng.load_state_dict(sd_np, numerics=choice)
+        xf = torch.from_numpy(T.synth_fbank(Bf, Tn, seed=1234)).to(dev).contiguous()
+        tq = sub_len(Tn)
+        of = torch.empty(Bf, tq, 256, device=dev)
+        lens = np.full(Bf, Tn, np.int32)
         eng.encoder_full(xf.data_ptr(), lens, Bf, Tn, of.data_ptr(), cs)
-    torch.cuda.synchronize()
-    df = (time.perf_counter() - t0) / 2
-    flops = Bf * 2.0 * (tq * (11.2e6 + 1.25e6 + 0.18e6 + 18.183168e6 + 9216.0 * tq))
-    legs["full_context"] = {"workload": f"configs[4]: full-context encoder, batch={Bf} x 30 s (decoding_chunk_size=-1), {tq} frames per utterance", "ms_per_step": round(df * 1e3, 2),
-                            "value": round(Bf * Tn / df, 1), "unit": "audio-frames/s", "dtype": choice,
-                            "roofline": {"bound": "mfma", "kernel": "whole encoder pass = the layer-major schedule with one chunk of T frames (gemm_bw conv2, ffn_as, gemm_as, rel_attention_lm_mfma over 749 keys, dwconv_lm)", "achieved": round(flops / df / 1e12, 2),
-                                         "peak": PEAK_TFLOPS[choice], "unit": "TFLOP/s", "frac": round(flops / df / 1e12 / PEAK_TFLOPS[choice], 4), "traffic": None}}
-    del eng, xf, of
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(2):
+            eng.encoder_full(xf.data_ptr(), lens, Bf, Tn, of.data_ptr(), cs)
+        torch.cuda.synchronize()
+        df = (time.perf_counter() - t0) / 2
+        flops = Bf * 2.0 * (tq * (11.2e6 + 1.25e6 + 0.18e6 + 18.183168e6 + 9216.0 * tq))
+        legs["full_context"] = {"workload": f"configs[4]: full-context encoder, batch={Bf} x 30 s (decoding_chunk_size=-1), {tq} frames per utterance", "ms_per_step": round(df * 1e3, 2),
+                                "value": round(Bf * Tn / df, 1), "unit": "audio-frames/s", "dtype": choice,
+                                "roofline": {"bound": "mfma", "kernel": "whole encoder pass = the layer-major schedule with one chunk of T frames (gemm_bw conv2, ffn_as, gemm_as, rel_attention_lm_mfma over 749 keys, dwconv_lm)", "achieved": round(flops / df / 1e12, 2),
+                                             "peak": PEAK_TFLOPS[choice], "unit": "TFLOP/s", "frac": round(flops / df / 1e12 / PEAK_TFLOPS[choice], 4), "traffic": None}}
+        del eng, xf, of
 
     # ---- joint lattice B64 x T249 x U28: the HBM-roofline kernel of north_star ---------------------------------------------------
-    Bj, Tj, U, V = 64, 249, 28, T.VOCAB
-    eng = RnntEngine(max_streams=Bj, max_chunk_frames=16, max_cache_frames=8, max_enc_frames=Tj + 64, vocab_size=V, blank_id=T.BLANK, device=local_rank)
-    eng.load_state_dict(sd_np, numerics=choice)
-    g = torch.Generator(device="cpu").manual_seed(5)
-    enc = torch.randn(Bj, Tj, 256, generator=g).to(dev)
-    prd = (torch.randn(Bj, U, 256, generator=g) * 0.5).to(dev)
-    lat = torch.empty(Bj, Tj, U, V, device=dev)
-    res = {}
-    for jm in (0, 1):
-        for _ in range(2):
-            eng.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+    if "joint" in want:
+        Bj, Tj, U, V = 64, 249, 28, T.VOCAB
+        g = torch.Generator(device="cpu").manual_seed(5)
+        enc = torch.randn(Bj, Tj, 256, generator=g).to(dev)
+        prd = (torch.randn(Bj, U, 256, generator=g) * 0.5).to(dev)
+        lat = torch.empty(Bj, Tj, U, V, device=dev)
+        cells = Bj * Tj * U
+        byts = 4.0 * (Bj * Tj * 256 + Bj * U * 256) + 4.0 * (2 * 256 * 256 + 256 * V + 2 * 256 + V) + 4.0 * cells * V
+
+        def joint_times(mode_name):
+            """(wall s of rnnt_joint, HIP-event s of the lattice kernel alone, its launches) per form: 0 logits, 1 log-softmax."""
+            e_ = RnntEngine(max_streams=Bj, max_chunk_frames=16, max_cache_frames=8, max_enc_frames=Tj + 64, vocab_size=V, blank_id=T.BLANK, device=local_rank)
+            e_.load_state_dict(sd_np, numerics=mode_name)
+            res = {}
+            for jm in (0, 1):
+                for _ in range(2):
+                    e_.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(5):
+                    e_.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / 5
+                e_.profile_begin(TAG_JOINT_OUT)          # HIP events around the lattice kernel's launch on its stream
+                for _ in range(5):
+                    e_.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
+                kms, kn = e_.profile_end()
+                res[jm] = (wall, kms * 1e-3 / max(kn, 1), int(kn))
+            return e_, res
+
+        eng, res = joint_times(choice)
+        lat_ref = torch.empty(Bj, Tj, U, V, device=dev)
+        eng.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, 0, lat_ref.data_ptr(), cs)
+        # the ceiling of any kernel that writes this lattice: a plain fill of the same bytes (torch fill_ on the caller's stream)
+        lat.fill_(0.0); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5):
-            eng.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
+            lat.fill_(1.0)
         torch.cuda.synchronize()
-        res[jm] = (time.perf_counter() - t0) / 5
-    cells = Bj * Tj * U
-    byts = 4.0 * (Bj * Tj * 256 + Bj * U * 256) + 4.0 * (2 * 256 * 256 + 256 * V + 2 * 256 + V) + 4.0 * cells * V
-    legs["joint_lattice"] = {"workload": f"joint lattice B={Bj} T={Tj} U={U} V={V} (SURVEY.md §8d): enc_ffn, pred_ffn, then ONE lattice kernel (tanh-add prologue, projection, log-softmax epilogue)",
-                             "dtype": choice, "logits_ms": round(res[0] * 1e3, 3), "log_softmax_ms": round(res[1] * 1e3, 3), "value": round(cells / res[1], 1), "unit": "lattice-cells/s (log-softmax form)",
-                             "roofline": {"bound": "hbm", "kernel": "rnnt_joint mode 1 (2 small GEMMs + the lattice kernel)", "achieved": round(byts / res[1] / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": round(byts / res[1] / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "algorithmic_bytes": round(byts),
-                                          "logits_form_achieved_GBs": round(byts / res[0] / 1e9, 1)}}
-    # the same lattice in the single-product bf16 perf mode (what north_star's ">= 60 % of HBM" presumes): time + max logit error vs the headline mode
-    lat_ref = torch.empty(Bj, Tj, U, V, device=dev)
-    eng.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, 0, lat_ref.data_ptr(), cs)
-    engb = RnntEngine(max_streams=Bj, max_chunk_frames=16, max_cache_frames=8, max_enc_frames=Tj + 64, vocab_size=V, blank_id=T.BLANK, device=local_rank)
-    engb.load_state_dict(sd_np, numerics="bf16")
-    resb = {}
-    for jm in (0, 1):
-        for _ in range(2):
-            engb.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(5):
-            engb.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, jm, lat.data_ptr(), cs)
+        t_fill = (time.perf_counter() - t0) / 5
+        kern = "joint_lattice_rows (rnnt_joint.hip.h)" if choice != "fp32" else "gemm_ns (tanh-add prologue) + log_softmax_rows"
+        pt = pmc_traffic(["void joint_lattice_rows"]) if choice != "fp32" else None
+        k1 = res[1][1]
+        legs["joint_lattice"] = {"workload": f"joint lattice B={Bj} T={Tj} U={U} V={V} (SURVEY.md §8d): enc_ffn, pred_ffn (two small GEMMs), then ONE lattice kernel (tanh-add operand formation, projection, log-softmax on the accumulators)",
+                                 "dtype": choice, "logits_ms": round(res[0][0] * 1e3, 3), "log_softmax_ms": round(res[1][0] * 1e3, 3), "value": round(cells / res[1][0], 1), "unit": "lattice-cells/s (log-softmax form, whole rnnt_joint call)",
+                                 "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(byts / k1 / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                              "frac": round(byts / k1 / 1e9 / PEAK_HBM_GBS, 4), "traffic": pt["traffic_bytes_per_launch"] if pt else None, "traffic_source": pt["source"] if pt else None,
+                                              "algorithmic_bytes": round(byts), "avg_launch_us": round(k1 * 1e6, 1), "launches_timed": res[1][2],
+                                              "timing": "HIP events around the lattice kernel on its launch stream (log-softmax form)",
+                                              "logits_form_avg_launch_us": round(res[0][1] * 1e6, 1), "logits_form_achieved_GBs": round(byts / res[0][1] / 1e9, 1),
+                                              "whole_call_frac": round(byts / res[1][0] / 1e9 / PEAK_HBM_GBS, 4),
+                                              "fill_of_the_same_bytes_us": round(t_fill * 1e6, 1), "fill_frac_of_peak": round(byts / t_fill / 1e9 / PEAK_HBM_GBS, 4),
+                                              "note": "the lattice is write-bound: a plain fill of its 735 MB is the ceiling of this kernel (fill_frac_of_peak)"}}
+        # the same lattice in the single-product bf16 perf mode (what north_star's ">= 60 % of HBM" presumes): time + max logit error vs the headline mode
+        engb, resb = joint_times("bf16")
+        engb.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, 0, lat.data_ptr(), cs)
         torch.cuda.synchronize()
-        resb[jm] = (time.perf_counter() - t0) / 5
-    engb.joint(enc.data_ptr(), prd.data_ptr(), Bj, Tj, U, 0, lat.data_ptr(), cs)
-    torch.cuda.synchronize()
-    legs["joint_lattice"]["bf16_perf_mode"] = {"logits_ms": round(resb[0] * 1e3, 3), "log_softmax_ms": round(resb[1] * 1e3, 3), "achieved_GBs": round(byts / resb[1] / 1e9, 1),
-                                               "frac_of_hbm": round(byts / resb[1] / 1e9 / PEAK_HBM_GBS, 4), "max_abs_logit_err_vs_headline_mode": float((lat - lat_ref).abs().max().item()),
-                                               "parity_gated": False}
-    del eng, engb, lat, lat_ref
+        legs["joint_lattice"]["bf16_perf_mode"] = {"logits_ms": round(resb[0][0] * 1e3, 3), "log_softmax_ms": round(resb[1][0] * 1e3, 3),
+                                                   "kernel_avg_launch_us": round(resb[1][1] * 1e6, 1), "achieved_GBs": round(byts / resb[1][1] / 1e9, 1),
+                                                   "frac_of_hbm": round(byts / resb[1][1] / 1e9 / PEAK_HBM_GBS, 4), "whole_call_frac": round(byts / resb[1][0] / 1e9 / PEAK_HBM_GBS, 4),
+                                                   "max_abs_logit_err_vs_headline_mode": float((lat - lat_ref).abs().max().item()), "parity_gated": False}
+        del eng, engb, lat, lat_ref
     out["legs"] = legs
 
     # ---- CPU baseline: the oracle on this host, B=1 streams serially (baseline only) -----------------------------------------------------------------

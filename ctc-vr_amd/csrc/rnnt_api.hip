@@ -117,7 +117,7 @@ struct rnnt_ctx {
     hipStream_t dec_stream = nullptr;          // decode runs here while the encoder wavefront runs on the caller's stream
     hipStream_t grp_stream[4] = {nullptr, nullptr, nullptr, nullptr};   // layer groups 1.. of the wavefront (group 0 = caller's stream)
     hipStream_t sub_stream = nullptr;          // subsampling slabs
-    int wf_groups = 2, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4), RNNT_WF_SUB_ASYNC
+    int wf_groups = 1, wf_sub_async = 1;       // RNNT_WF_GROUPS (1..4; default 1: see api_encoder.hip.inc), RNNT_WF_SUB_ASYNC
     int wf_merge = 2;                          // RNNT_WF_MERGE (1..WF_MERGE_MAX): chunks of one layer per wavefront stage
     // descriptor tables of the last rnnt_encoder_chunks call, reused when the next call has the same plan and entry state
     struct WfLaunch { int type, off, n, maxM, maxT2; };   // type 0..7 gemm (ffn1m ffn2m qkv out pw1 pw2 ffn1 ffn2), 10 attn, 11 dw, 12 ln

@@ -137,8 +137,6 @@ static void problem(const char* title, int M, int N, int K, bool ln, int epi) {
     auto r22 = run<2, 2>("<2,2>", p, 20);
     reference(p, r22, "<2,2>");
     auto r12 = run<1, 2>("<1,2>", p, 20);
-    auto r42 = r22, r44 = r22;
-    if (!ln) { r42 = run<4, 2>("<4,2>", p, 20); r44 = run<4, 4>("<4,4>", p, 20); }
     const bool as_ok = (K == 256 || (K % 256 == 0 && N == 256)) && N % 64 == 0;
     std::vector<float> a4 = r22, a3 = r22;
     if (as_ok) { a4 = run_as<4>("as<4>", p, 20); reference(p, a4, "as<4>"); a3 = run_as<3>("as<3>", p, 20); }
@@ -153,7 +151,7 @@ static void problem(const char* title, int M, int N, int K, bool ln, int epi) {
             if (cnt) { printf("      row %zu (tile %zu, row-in-tile %zu): %d cols [%d..%d] max diff %.3e\n", m, m / 128, m % 128, cnt, c0, c1, mx); ++shown; }
         }
     };
-    cmp("<1,2>", r12); cmp("<4,2>", r42); cmp("<4,4>", r44);
+    cmp("<1,2>", r12);   // (the 128-row tiles <4,2> / <4,4> of round 2 are gone: see host_launch.hip.inc)
     if (as_ok) {
         cmp("as<4>", a4); cmp("as<3>", a3);
         double mx = 0; for (size_t e = 0; e < a4.size(); ++e) mx = std::max(mx, (double)fabs(a4[e] - r22[e]));
