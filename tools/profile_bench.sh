@@ -1,13 +1,13 @@
 # Profile the bench command on the GPU box (run through gpurun from the repo root): per-kernel times, then PMC counters in
 # their own passes (never combined with trace domains).  Two commands: the default bench step (encoder + decoder kernels) and
 # the joint-lattice leg (--legs joint), so every roofline object of the bench line has a `traffic` figure.
-#   usage: bash tools/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/ ; summaries via tools/{pmc,mfma}_summary.py
+#   usage: bash tools/profile_bench.sh <tag> ["step joint"]      -> gpurun_out/prof_<tag>/ ; summaries via tools/{pmc,mfma}_summary.py
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_${1:-x}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for leg in step joint; do
+for leg in ${2:-step joint}; do
   if [ $leg = step ]; then CMD="python3 $R/bench.py --no-legs --no-cpu --numerics bf16x3 --steps 10"; else CMD="python3 $R/bench.py --legs joint --no-cpu --numerics bf16x3 --steps 2 --in-flight 1"; fi
   rocprofv3 --kernel-trace --stats -d $O/kt_$leg -o kt -- $CMD > $O/bench_kt_$leg.json 2> $O/kt_$leg.err
   echo kt $leg done
