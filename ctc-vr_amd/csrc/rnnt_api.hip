@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <algorithm>
 #include <array>
@@ -57,7 +58,7 @@ struct rnnt_ctx {
     unsigned char* joint_wfrag = nullptr;     // joint.ffn_out as the LDS-DMA ring's stage stream (pack_joint_w), split modes and bf16
     size_t joint_wfrag_bytes = 0;
     int* joint_counter = nullptr;             // joint_lattice_rows' dynamic row-tile queue (zeroed before every launch)
-    bool joint_attr[2] = {false, false};      // dynamic-LDS attribute set for the current mode's (logits, log-softmax) kernels
+    std::map<const void*, int> dyn_lds;       // kernels whose dynamic-LDS limit was raised for THIS context's device (ensure_dyn_lds)
     std::vector<LayerDev> layers_host;        // host copy (packed-weight pointers for gemm_as / ffn_as launches)
     int use_as = 1;                            // RNNT_AS=0: LDS-tiled gemm_bf for every layer contraction of the layer-major schedule
     int use_fused = 1;                         // RNNT_FUSED=0: the unfused wavefront (11 launches per stage)
@@ -87,6 +88,7 @@ struct rnnt_ctx {
     int fuse_after_norm = 1;   // RNNT_FUSE_AFTER_NORM=0: keep after_norm as its own launch in the pipelined greedy path
     int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
+    bool holds_dec_lock = false;   // this context's greedy_multi grid is between launch and finish (dec_device_lock)
     int use_multi = 1;         // RNNT_DEC_MULTI=0: one CU per stream (greedy_stream) instead of greedy_multi (4 CUs per stream)
     int n_cus = 0;
     unsigned long long *gm_x1 = nullptr, *gm_xa = nullptr;   // greedy_multi mailboxes

@@ -355,8 +355,6 @@ class OnlineRNNTModel:
         s = _stream_ptr()
         enc = torch.empty(1, tq, 256, device=dev)
         eng.encoder_full(x.data_ptr(), np.asarray([int(audio_lens[0])], np.int32), 1, T, enc.data_ptr(), s)
-        n1 = (int(audio_lens[0]) - 1) // 2
-        n_valid = (n1 - 1) // 2                                  # frames the padding mask keeps (subsampling.py:228)
         ctc_dev = torch.empty(tq, V, device=dev)
         eng.ctc_logprobs(enc.data_ptr(), tq, ctc_dev.data_ptr(), s)
         ctc = ctc_dev.cpu()
@@ -369,7 +367,7 @@ class OnlineRNNTModel:
                 return -float("inf")
             a_max = max(args)
             return a_max + math.log(sum(math.exp(a - a_max) for a in args))
-        for i in range(min(tq, n_valid) if n_valid > 0 else tq):
+        for i in range(tq):                                      # every encoder frame, padded ones included (maxlen = encoder_out.size(1), :64,76)
             n = len(hyps)
             tok = torch.tensor([hy[-1] for hy in hyps], dtype=torch.int32, device=dev)
             pred, h2, c2 = torch.empty(n, 256, device=dev), torch.empty(n, 256, device=dev), torch.empty(n, 256, device=dev)

@@ -239,6 +239,25 @@ def gen_streams(inputs):
 
 
 @torch.no_grad()
+def gen_streaming_beam(inputs):
+    """OnlineRNNTModel.streaming_beam_search (model/online_rnnt_model.py:534-603): whole-utterance beam search with
+    streaming_inference's chunking (static_chunk_size * 4 input frames, or chunk_size_ms); best hypothesis + every final one."""
+    syn = torch.from_numpy(T.synth_fbank(2, 1000))
+    for name, seed, x, scs, ms, beam in (("beam_si_ex6_scs16_s0", 0, inputs["ex6"], 16, None, 4),
+                                         ("beam_si_syn1_scs16_s1_f400", 1, syn[1:2, :400], 16, None, 4),
+                                         ("beam_si_ex6_scs32_ms200_s0", 0, inputs["ex6"], 32, 200, 3)):
+        net = build(seed, scs)
+        t0 = time.time()
+        r, _, _ = net.streaming_beam_search(x, torch.tensor([x.shape[1]]), beam_size=beam, chunk_size_ms=ms)
+        hyps = net.streaming_beam_hypotheses
+        flat, cnt = pack_tokens([[int(t) for t in h.tokens] for h in hyps])
+        print(f"{name}: best {len(r[0])} tokens, {len(hyps)} final hypotheses, {time.time() - t0:.1f}s")
+        save(f"{name}.npz", tokens=np.array(r[0], np.int64), static_chunk_size=np.int64(scs), chunk_size_ms=np.int64(-1 if ms is None else ms),
+             seed=np.int64(seed), beam=np.int64(beam), frames=np.int64(x.shape[1]),
+             hyp_tokens=flat, hyp_counts=cnt, hyp_logp=np.array([float(h.log_prob) for h in hyps], np.float64))
+
+
+@torch.no_grad()
 def gen_full(inputs):
     net = build(0, 16)
     syn = torch.from_numpy(T.synth_fbank(2, 300, seed=99))
@@ -348,13 +367,15 @@ def gen_prefix():
         a_max = max(args)
         return a_max + math.log(sum(math.exp(a - a_max) for a in args))
     pbs_mod.log_add = log_add_list
-    for seed, frames, beam in ((0, 240, 4), (1, 171, 5)):
+    # (seed, frames of the padded input, valid frames, beam, file tag): the third case is a PADDED utterance (audio_lens < T): the
+    # reference iterates every encoder frame, the padded ones included (prefix_beam_search.py:64,76)
+    for seed, frames, valid, beam, tag in ((0, 240, 240, 4, "seed0"), (1, 171, 171, 5, "seed1"), (0, 240, 187, 4, "seed0_padded")):
         net = build(seed, 16)
         x = torch.from_numpy(T.synth_fbank(1, frames, seed=55 + seed))
         pbs = PrefixBeamSearch(net.encoder, net.predictor, net.joint, net.ctc_head, net.blank_id)
-        beam_out, enc = pbs.prefix_beam_search(x, torch.tensor([frames]), decoding_chunk_size=-1, beam_size=beam, ctc_weight=0.3, transducer_weight=0.7)
+        beam_out, enc = pbs.prefix_beam_search(x, torch.tensor([valid]), decoding_chunk_size=-1, beam_size=beam, ctc_weight=0.3, transducer_weight=0.7)
         flat, cnt = pack_tokens([[int(t) for t in s.hyp] for s in beam_out])
-        save(f"prefix_beam_seed{seed}.npz", frames=np.int64(frames), fbank_seed=np.int64(55 + seed), beam=np.int64(beam), hyp_tokens=flat, hyp_counts=cnt,
+        save(f"prefix_beam_{tag}.npz", frames=np.int64(frames), valid_frames=np.int64(valid), fbank_seed=np.int64(55 + seed), beam=np.int64(beam), hyp_tokens=flat, hyp_counts=cnt,
              scores=np.array([float(s.score) for s in beam_out], np.float64), enc_frames=np.int64(enc.size(1)),
              h=f32(torch.cat([s.cache[0] for s in beam_out], 1)), c=f32(torch.cat([s.cache[1] for s in beam_out], 1)))
 
@@ -367,6 +388,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "offline":
         gen_offline()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "beam_si":
+        ex = {k: torch.from_numpy(v)[None] for k, v in np.load(os.path.join(HERE, "inputs_example1.npz")).items()}
+        gen_streaming_beam(ex)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("ctc", "prefix"):
         (gen_ctc if sys.argv[1] == "ctc" else gen_prefix)()
         sys.exit(0)
@@ -374,6 +399,7 @@ if __name__ == "__main__":
     gen_modules(0, inp)
     gen_modules(1, inp)
     gen_streams(inp)
+    gen_streaming_beam(inp)
     gen_full(inp)
     gen_cer()
     gen_offline()

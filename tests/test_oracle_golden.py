@@ -139,6 +139,23 @@ def test_streaming_inference(name, sds):
     assert tuple(st.att_cache.shape) == tuple(g["att_cache_shape"])
 
 
+@pytest.mark.parametrize("name", ["beam_si_ex6_scs16_s0", "beam_si_syn1_scs16_s1_f400", "beam_si_ex6_scs32_ms200_s0"])
+def test_streaming_beam_search(name, sds):
+    """OnlineRNNTModel.streaming_beam_search (model/online_rnnt_model.py:534-603): best hypothesis and every final hypothesis
+    (tokens in the reference's order, Python-double scores)."""
+    g = load_golden(f"{name}.npz")
+    sd = sds[int(g["seed"])]
+    x = stream_input(name[8:])[:, :int(g["frames"])]
+    st = O.OracleStream(sd, T.BLANK, int(g["static_chunk_size"]))
+    ms = int(g["chunk_size_ms"])
+    toks = st.streaming_beam_search(x, x.shape[1], int(g["beam"]), None if ms < 0 else ms)
+    assert toks == g["tokens"].tolist()
+    cnt, flat = g["hyp_counts"].tolist(), g["hyp_tokens"].tolist()
+    want = [flat[sum(cnt[:k]):sum(cnt[:k + 1])] for k in range(len(cnt))]
+    assert [h.tokens for h in st.beam] == want
+    assert np.allclose([h.log_prob for h in st.beam], g["hyp_logp"], atol=2e-3)
+
+
 @pytest.mark.parametrize("name", ["beam_ex6_c16_s0", "beam_syn0_c16_s1_f320", "beam_ex0_c32_s0"])
 def test_beam_search(name, sds):
     g = load_golden(f"{name}.npz")
@@ -205,15 +222,15 @@ def test_ctc_head_matches_reference(seed):
     assert np.abs(lp[:, :8].numpy() - g["logp_first8"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", ["0", "1", "0_padded"])
 def test_prefix_beam_search_matches_reference(seed):
     """oracle prefix_beam_search_full vs the reference's PrefixBeamSearch.prefix_beam_search run on the model's own encoder /
     predictor / joint / CTC head (golden prefix_beam_seed*.npz; the generator rebinds the name log_add in that module to the list
     form its call site uses, see gen_golden.py): hypotheses exact, scores to 1e-4, final predictor states to 1e-4."""
-    g = load_golden(f"prefix_beam_seed{seed}.npz")
-    sd = O.to_torch_sd(T.make_state_dict(seed))
+    g = load_golden(f"prefix_beam_seed{seed}.npz")    # "_padded": audio_lens < T, the search still walks every encoder frame
+    sd = O.to_torch_sd(T.make_state_dict(int(seed[0])))
     x = torch.from_numpy(T.synth_fbank(1, int(g["frames"]), seed=int(g["fbank_seed"])))
-    beam = O.prefix_beam_search_full(sd, x, torch.tensor([int(g["frames"])]), T.BLANK, beam_size=int(g["beam"]))
+    beam = O.prefix_beam_search_full(sd, x, torch.tensor([int(g["valid_frames"])]), T.BLANK, beam_size=int(g["beam"]))
     want, o = [], 0
     for c in g["hyp_counts"].tolist():
         want.append(g["hyp_tokens"][o:o + c].tolist())
