@@ -249,9 +249,10 @@ def main():
     sd0 = T.make_state_dict(0, blank_bias=args.blank_bias) if rank == 0 else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sd_np = D.broadcast_state_dict(sd0, src=0, device=dev)
+    wblob, wvocab = D.broadcast_packed(sd0, src=0, device=dev)     # the blob stays on this rank's device: contexts take it in one call
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
+    sd_np = sd0 if sd0 is not None else D.unpack_state_dict(wblob.cpu().numpy(), wvocab)   # name -> array view for the secondary legs' engines
 
     B = args.batch
     plan = T.chunk_plan(args.frames, args.chunk)
@@ -264,8 +265,8 @@ def main():
     def make_sb(mode, chunk=args.chunk, frames=args.frames, max_beam=0, max_tokens=None, batch=B):
         pl = T.chunk_plan(frames, chunk)
         ef = sum(sub_len(b - a) for a, b in pl)
-        return StreamingBatch(sd_np, batch, max_chunk_frames=max(b - a for a, b in pl), max_cache_frames=ef + 8, max_enc_frames=ef + 8,
-                              max_tokens=max_tokens or ef * 10 + 16, device=local_rank, max_beam=max_beam, numerics=mode)
+        return StreamingBatch(None, batch, vocab_size=wvocab, max_chunk_frames=max(b - a for a, b in pl), max_cache_frames=ef + 8, max_enc_frames=ef + 8,
+                              max_tokens=max_tokens or ef * 10 + 16, device=local_rank, max_beam=max_beam, numerics=mode, packed=(wblob, wvocab))
 
     # ---- parity gate: one untimed pass per mode -> tokens, first-call time; encoder error vs fp32 ----------------------------
     modes = ["fp32", "bf16x3", "f16x3", "bf16"] if args.numerics == "auto" else sorted({"fp32", args.numerics}, key=["fp32", "bf16x3", "f16x3", "bf16"].index)

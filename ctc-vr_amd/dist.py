@@ -4,7 +4,7 @@ the GPU box: torch.distributed backend "nccl"; gloo on CPU in the tests)."""
 import numpy as np
 import torch
 
-from . import testing as T
+from . import layout as T
 
 
 def vocab_of(sd):
@@ -51,12 +51,15 @@ def blob_size(vocab=T.VOCAB):
     return sum(int(np.prod(s)) if s else 1 for _, s, _ in T.state_dict_spec(vocab))
 
 
-def broadcast_state_dict(sd, src=0, device="cpu"):
-    """Rank `src` passes its state dict (others pass None); every rank returns the same dict.  The layout is derived on the
-    source rank: a 2-word header (vocabulary size, blob length) goes first, then ONE dist.broadcast of the ~88 MB float32 blob."""
+def broadcast_packed(sd, src=0, device="cpu"):
+    """Rank `src` passes its state dict (others pass None); every rank returns (blob, vocab): the packed float32 blob as a torch
+    tensor ON `device` (it never visits the host on the receiving ranks) and the vocabulary size.  The layout is derived on the
+    source rank: a 2-word header (vocabulary size, blob length) goes first, then ONE dist.broadcast of the ~88 MB blob (RCCL over
+    xGMI with the "nccl" backend).  Hand the pair to RnntEngine.load_packed / StreamingBatch(packed=...): one C-ABI call."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return sd
+        vocab = vocab_of(sd)
+        return torch.from_numpy(pack_state_dict(sd, vocab)).to(device), vocab
     is_src = dist.get_rank() == src
     hdr_dev = device if dist.get_backend() == "nccl" else "cpu"
     if is_src:
@@ -69,8 +72,18 @@ def broadcast_state_dict(sd, src=0, device="cpu"):
     vocab, n = int(hdr[0]), int(hdr[1])
     if n != blob_size(vocab):
         raise ValueError(f"source rank announced {n} floats for vocab {vocab}; this rank's layout has {blob_size(vocab)}")
-    blob = torch.from_numpy(flat).to(device) if is_src else torch.empty(n, dtype=torch.float32, device=device)
+    bdev = device if dist.get_backend() == "nccl" else "cpu"           # gloo broadcasts host tensors
+    blob = torch.from_numpy(flat).to(bdev) if is_src else torch.empty(n, dtype=torch.float32, device=bdev)
     dist.broadcast(blob, src=src)
+    return blob.to(device), vocab
+
+
+def broadcast_state_dict(sd, src=0, device="cpu"):
+    """broadcast_packed, unpacked into a name -> numpy dict on every rank (for callers that build several contexts from it)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    blob, vocab = broadcast_packed(sd, src=src, device=device)
     return unpack_state_dict(blob.cpu().numpy(), vocab)
 
 

@@ -23,6 +23,7 @@ SIGNATURES = {
     "rnnt_last_error": (ctypes.c_char_p, [c_vp]),
     "rnnt_abi_version": (c_i32, []),
     "rnnt_load_tensor": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i32, ctypes.POINTER(c_i64)]),
+    "rnnt_load_packed": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
     "rnnt_finalize_weights": (c_i32, [c_vp, c_i32, c_vp]),
     "rnnt_streams_reset": (c_i32, [c_vp, c_i32, c_vp]),
     "rnnt_encoder_chunk": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32p, c_vp]),
@@ -150,6 +151,26 @@ class RnntEngine:
             a = np.ascontiguousarray(v, dtype=np.float32)
             dims = (c_i64 * max(a.ndim, 1))(*a.shape)
             self._chk(self.lib.rnnt_load_tensor(self.ctx, name.encode(), _np_ptr(a), a.ndim, dims), f"rnnt_load_tensor({name})")
+        self.numerics = numerics_id(numerics)
+        self._chk(self.lib.rnnt_finalize_weights(self.ctx, self.numerics, stream), "rnnt_finalize_weights")
+
+    def load_packed(self, blob, vocab, stream=None, numerics=None):
+        """The whole state dict from ONE flat float32 blob in layout.state_dict_spec(vocab) order (num_batches_tracked slots are
+        one float each and ignored): a torch tensor on this context's device (the blob dist.broadcast_packed leaves there) or a
+        numpy array on the host.  One C-ABI call (rnnt_load_packed), then rnnt_finalize_weights."""
+        from .layout import state_dict_spec
+        spec = state_dict_spec(vocab)
+        names = (ctypes.c_char_p * len(spec))(*[n.encode() for n, _, _ in spec])
+        ndims = (c_i32 * len(spec))(*[len(s) for _, s, _ in spec])
+        flat = [d for _, s, _ in spec for d in s]
+        dims = (c_i64 * max(len(flat), 1))(*flat)
+        if hasattr(blob, "data_ptr"):
+            assert blob.dtype.is_floating_point and blob.element_size() == 4 and blob.is_contiguous()
+            ptr, n, on_dev = blob.data_ptr(), blob.numel(), 1 if blob.is_cuda else 0
+        else:
+            blob = np.ascontiguousarray(blob, np.float32)
+            ptr, n, on_dev = _np_ptr(blob), blob.size, 0
+        self._chk(self.lib.rnnt_load_packed(self.ctx, ptr, n, on_dev, len(spec), names, ndims, dims), "rnnt_load_packed")
         self.numerics = numerics_id(numerics)
         self._chk(self.lib.rnnt_finalize_weights(self.ctx, self.numerics, stream), "rnnt_finalize_weights")
 

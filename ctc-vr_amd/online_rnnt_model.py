@@ -422,7 +422,9 @@ class StreamingBatch:
 
     def __init__(self, state_dict, n_streams: int, vocab_size: int = 412, blank_id: int = 5, max_chunk_frames: int = 64,
                  max_cache_frames: int = 512, max_enc_frames: int = 512, max_tokens: int = 4096, device: int = 0, max_beam: int = 0,
-                 numerics=None):
+                 numerics=None, packed=None):
+        """state_dict: the reference's 504-key dict (numpy / torch values), or None with packed=(blob, vocab): the flat float32
+        blob dist.broadcast_packed left on this rank's device, handed to the context in one call (RnntEngine.load_packed)."""
         self.device = torch.device("cuda", device)
         self.n = n_streams
         self.blank_id = blank_id
@@ -431,7 +433,11 @@ class StreamingBatch:
                                  n_steps=10, device=device, max_beam=max_beam)
         self.beams = None
         self.python_beam = False      # True: host half of the beam search in Python (beam_advance_frame), for tests
-        self.engine.load_state_dict(state_dict, numerics=numerics)
+        if packed is not None:
+            assert state_dict is None and int(packed[1]) == vocab_size, "packed=(blob, vocab): vocab must equal vocab_size"
+            self.engine.load_packed(packed[0], int(packed[1]), numerics=numerics)
+        else:
+            self.engine.load_state_dict(state_dict, numerics=numerics)
         self.offset = 0
 
     def reset(self):
@@ -466,7 +472,7 @@ class StreamingBatch:
         pipelined=True: the whole utterance's encoder in one rnnt_encoder_chunks call, then ONE rnnt_beam_advance over
         all frames (same hypotheses: the beam recursion only consumes encoder frames in order); needs
         max_enc_frames >= the utterance's encoder frames."""
-        from .testing import chunk_plan
+        from .layout import chunk_plan
         self.reset()
         if pipelined and not self.python_beam:
             assert audios.is_cuda and audios.dtype == torch.float32 and audios.is_contiguous()
@@ -532,7 +538,7 @@ class StreamingBatch:
         (identical tokens: the greedy state machine is causal in the frame index).
         pipelined=True hands the whole chunk plan to rnnt_encoder_chunks (wavefront over chunk x layer,
         bit-identical encoder output) and decodes once."""
-        from .testing import chunk_plan
+        from .layout import chunk_plan
         self.reset()
         T = audios.size(1)
         if pipelined:

@@ -77,6 +77,13 @@ int rnnt_abi_version(void);
  * (num_batches_tracked entries are accepted and ignored). */
 int rnnt_load_tensor(rnnt_ctx* ctx, const char* name, const float* host_data, int32_t ndim,
                      const int64_t* dims);
+/* The whole state dict in ONE call from a flat float32 blob (the packed blob of the multi-GPU weight broadcast, SURVEY.md §8e:
+ * rank 0 broadcasts it over RCCL, every rank hands its device copy to its context).  blob: n_floats floats, on the context's
+ * device (on_device != 0) or on the host; tensor i is `names[i]` with `ndims[i]` dimensions taken in order from dims_flat and
+ * starts where tensor i-1 ends.  Equivalent to n_tensors calls of rnnt_load_tensor (one device-to-host copy instead of none:
+ * the packing below needs the values on the host).  Fails with RNNT_ERR_SHAPE if the table does not cover exactly n_floats. */
+int rnnt_load_packed(rnnt_ctx* ctx, const float* blob, int64_t n_floats, int32_t on_device, int32_t n_tensors,
+                     const char* const* names, const int32_t* ndims, const int64_t* dims_flat);
 /* packs weights for the kernels (BatchNorm fold, linear_pos table pe*W_pos^T, LSTM input table,
  * GLU/LSTM row interleave, conv2 channels-last) and uploads them.  Fails with RNNT_ERR_STATE if
  * any required tensor is missing. */

@@ -31,6 +31,10 @@ def _worker(rank, world, port, q):
     got2 = D.broadcast_state_dict(sd2, src=0, device="cpu")
     ref2 = T.make_state_dict(4, vocab=77, blank=3)
     same = same and got2["joint.ffn_out.weight"].shape == (77, 256) and all(np.array_equal(got2[k], ref2[k]) for k in got2)
+    # the packed form every GPU rank hands to its context in one call (RnntEngine.load_packed): blob + vocabulary
+    blob, vocab = D.broadcast_packed(T.make_state_dict(3) if rank == 0 else None, src=0, device="cpu")
+    same = same and vocab == T.VOCAB and blob.dtype == torch.float32 and blob.numel() == D.blob_size(vocab) \
+        and np.array_equal(blob.numpy(), D.pack_state_dict(ref))
     lo, hi = D.shard_range(130, rank, world)
     # every rank decodes only its own streams; a tiny all_gather of counts stands in for result collection
     mine = torch.tensor([hi - lo], dtype=torch.int64)

@@ -749,6 +749,22 @@ def test_large_stream_count_whole_utterance(np_state_dict):
         assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), i
 
 
+def test_packed_blob_ingest(np_state_dict):
+    """rnnt_load_packed (the multi-GPU weight path: dist.broadcast_packed leaves the packed blob on the device, the context takes it
+    in one call): same tokens as the per-tensor ingest, from a device blob and from a host blob; a wrong table is an error."""
+    import ctc_vr_amd.dist as Dm
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    sd = np_state_dict(0)
+    x = torch.from_numpy(T.synth_fbank(2, 160, seed=77)).cuda().contiguous()
+    kw = dict(max_chunk_frames=32, max_cache_frames=64, max_enc_frames=64)
+    want = StreamingBatch(sd, 2, **kw).decode_script(x, 16)
+    flat = Dm.pack_state_dict(sd)
+    for blob in (torch.from_numpy(flat).cuda(), flat):
+        assert StreamingBatch(None, 2, packed=(blob, T.VOCAB), **kw).decode_script(x, 16) == want
+    with pytest.raises(Exception):
+        StreamingBatch(None, 2, packed=(torch.from_numpy(flat[:-8]).cuda(), T.VOCAB), **kw)
+
+
 @pytest.mark.parametrize("n", [16, 64])
 def test_two_contexts_in_flight(n, np_state_dict):
     """Two contexts driven by two host threads on two HIP streams at the same time (how bench.py keeps two batches in flight:
