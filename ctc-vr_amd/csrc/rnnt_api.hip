@@ -11,7 +11,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <mutex>
 #include <string>
 #include <algorithm>
 #include <array>
@@ -88,7 +87,6 @@ struct rnnt_ctx {
     int fuse_after_norm = 1;   // RNNT_FUSE_AFTER_NORM=0: keep after_norm as its own launch in the pipelined greedy path
     int overlap_ok = -1;       // -1 not probed; 1: kernels of the decode stream run concurrently with the caller's stream
     int use_coop = 0;          // RNNT_COOP=1: cooperative weights-stationary decoder (n_streams <= 64), experiment
-    bool holds_dec_lock = false;   // this context's greedy_multi grid is between launch and finish (dec_device_lock)
     int use_multi = 1;         // RNNT_DEC_MULTI=0: one CU per stream (greedy_stream) instead of greedy_multi (4 CUs per stream)
     int n_cus = 0;
     unsigned long long *gm_x1 = nullptr, *gm_xa = nullptr;   // greedy_multi mailboxes

@@ -81,6 +81,10 @@ struct GemmP {
     // host-computed: addressing fast paths (no integer division in the kernel) and division magics
     // (q = umulhi(n, magic), exact while n*d < 2^32; see fastdiv()).
     int a_plain, c_plain;
+    // padding mask of the conv module's output (convolution.py:148-150, full-context pass): row m = b * rowlen_n + f is stored only
+    // if f < rowlen[b] (null: every row).  The masked rows keep their residual input: x += 0.
+    const int* rowlen;
+    int rowlen_n;
     int lstm_ld;   // EPI_LSTM: row stride (floats) of X2 / C / Y2; 0 -> 256
     // greedy decode: per-row buffer select (LSTM state ping-pong) and fused argmax
     const int* Asel;             // [M] 0/1: A row m lives in buffer Asel[m] (^ asel_invert); null = off
@@ -138,7 +142,13 @@ __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic, int shift) 
     return d == 1 ? n : (int)(__umulhi((unsigned)n, magic) >> shift);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// ONE logistic function for every kernel of the library (SiLU of the FFN / conv module, GLU gate, LSTM gates), in every numerics
+// mode: 1 / (1 + 2^(-x log2 e)) on the hardware v_exp_f32 / v_rcp_f32 (1 ulp each; |error| < 3e-7 absolute), 5 VALU instead of the
+// ~25 of `1.0f / (1.0f + expf(-x))` (libm expf + IEEE division) -- in ffn_as that epilogue alone was ~2.8 VALU per MFMA.
+// Because every path (per-chunk API, layer-major whole-utterance schedule, wavefront fallback, resident decoders) calls THIS
+// function, results that must agree bitwise between those paths still do (round 2 tried the fast form in ffn_as only, which
+// moved a near-tie token relative to the per-chunk path, and dropped it).  exp2(+inf) = inf -> rcp -> 0; exp2(-inf) = 0 -> 1.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

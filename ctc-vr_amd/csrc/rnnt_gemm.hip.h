@@ -265,6 +265,7 @@ __device__ __forceinline__ void gemm16_body(const GemmP& p) {
             continue;
         }
         if (!inb) continue;
+        if (p.rowlen) { const int b_ = m / p.rowlen_n; if (m - b_ * p.rowlen_n >= ldgi(p.rowlen + b_)) continue; }   // padded frame (see GemmP::rowlen)
         const long long crow = c_row_off(p, m);
         float v = sum + (p.bias ? ldg1(p.bias + n) : 0.f);
         if (epi == EPI_SILU) v = v * sigmoidf_(v);
@@ -307,7 +308,8 @@ __device__ __forceinline__ void ns_epilogue(const GemmP& p, const f32x4_ (&acc)[
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 16 * mt + 4 * kq + r;
-                const bool inb = nin && m < p.M;
+                bool inb = nin && m < p.M;
+                if (p.rowlen && inb) { const int b_ = m / p.rowlen_n; inb = m - b_ * p.rowlen_n < ldgi(p.rowlen + b_); }
                 float v = acc[mt][t][r] + bias;
                 if (epi == EPI_GLU) {
                     const float g = __shfl_xor(v, 1, 64);               // (value, gate) in adjacent columns / lanes

@@ -775,7 +775,7 @@ def test_two_contexts_in_flight(n, np_state_dict):
     g0, g1 = load_golden("stream_syn0_c16_s0.npz"), load_golden("stream_syn1_c16_s0.npz")
     syn = torch.from_numpy(T.synth_fbank(2, 1000))
     # n = 64: the configuration bench.py and INTEGRATION.md recommend -- two resident 256-workgroup decoder grids wanted by two
-    # contexts on 256 CUs; the library runs one decoder grid per device at a time (dec_device_lock, host_launch.hip.inc)
+    # contexts on 256 CUs (why that is safe: multi_decoder_ok's comment in host_launch.hip.inc)
     x = torch.stack([syn[i % 2] for i in range(n)]).cuda().contiguous()
     want = [(g0, g1)[i % 2]["tokens"].tolist() for i in range(n)]
     sbs = [StreamingBatch(np_state_dict(0), n, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256, max_tokens=2048) for _ in range(2)]
