@@ -130,6 +130,10 @@ struct rnnt_ctx {
     int use_lm = 1;                            // RNNT_LM=0: wavefront schedule for every whole-utterance call
     float *lm_x = nullptr, *lm_h = nullptr, *lm_q = nullptr, *lm_a = nullptr, *lm_d = nullptr, *lm_g = nullptr, *lm_y1 = nullptr, *lm_y2 = nullptr;
     size_t lm_y1_cap = 0, lm_y2_cap = 0, lm_blocks_cap = 0;
+    // ragged batches (rnnt_decode_ragged): gathered tail frames, their subsampled rows, gather / scatter entries
+    float *rg_fb = nullptr, *rg_xt = nullptr;
+    int2* rg_ent = nullptr;
+    size_t rg_fb_cap = 0, rg_xt_cap = 0, rg_ent_cap = 0;
     LmBlock* lm_blocks = nullptr;
     std::vector<LmBlock> lm_blocks_host;
     std::vector<int> lm_key;

@@ -38,7 +38,35 @@ struct LmAttnP {
     int F;
     long long kv_stride;
     const int* klen;     // per-stream number of valid keys counted from a row's ks (full-context padding mask); null = no limit
+    int per_stream;      // 0: one block table for every stream; 1: `blocks` is [B][gridDim.y] (ragged batch: every stream has its own chunk plan)
 };
+
+// ------------------------------------------------------------------------------------------------
+// Ragged batches (rnnt_decode_ragged): every stream's LAST chunk has its own start and length (online_rnnt_decode.py:88-91 merges
+// a short remainder into it), so the tails are subsampled per tail-length class: their fbank frames are gathered into a compact
+// [n][len][80] buffer, run through the ordinary subsampling of one chunk, and the resulting encoder-input rows scattered to the
+// stream's rows of the layer-major activation buffer.  ent = (stream, first fbank frame / first destination frame).
+// ------------------------------------------------------------------------------------------------
+__global__ void lm_gather_tails(const float* __restrict__ fbank, float* __restrict__ dst, const int2* __restrict__ ent, int n, int len, int Tstride) {
+    const long long tot = (long long)n * len * RNNT_IDIM;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < tot; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id % RNNT_IDIM);
+        const long long r = id / RNNT_IDIM;
+        const int t = (int)(r % len), v = (int)(r / len);
+        const int2 e = ent[v];
+        dst[id] = ldg1(fbank + ((long long)e.x * Tstride + e.y + t) * RNNT_IDIM + c);
+    }
+}
+__global__ void lm_scatter_rows(const float* __restrict__ src, float* __restrict__ x, const int2* __restrict__ ent, int n, int tq, int F) {
+    const long long tot = (long long)n * tq * RNNT_D;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < tot; id += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(id & 255);
+        const long long r = id >> 8;
+        const int t = (int)(r % tq), v = (int)(r / tq);
+        const int2 e = ent[v];
+        x[((long long)e.x * F + e.y + t) * RNNT_D + c] = src[id];
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // lm_ctx_in: the 30-row left context of every layer's linear post-GLU buffer <- the stream's ring rows before `pos`
@@ -143,7 +171,7 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int qt = wave & 1, hf = wave >> 1;
-    const LmBlock* __restrict__ blk = P.blocks + blockIdx.y;
+    const LmBlock* __restrict__ blk = P.blocks + (P.per_stream ? (long long)b * gridDim.y : 0) + blockIdx.y;
     const int amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
     // softmax role: rows 8*wave .. +7, each with its own key window
     int s_ks[8], s_ke[8], s_prel[8];

@@ -23,6 +23,7 @@ SIGNATURES = {
     "rnnt_last_error": (ctypes.c_char_p, [c_vp]),
     "rnnt_abi_version": (c_i32, []),
     "rnnt_load_tensor": (c_i32, [c_vp, ctypes.c_char_p, c_vp, c_i32, ctypes.POINTER(c_i64)]),
+    "rnnt_decode_ragged": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rnnt_load_packed": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
     "rnnt_finalize_weights": (c_i32, [c_vp, c_i32, c_vp]),
     "rnnt_streams_reset": (c_i32, [c_vp, c_i32, c_vp]),
@@ -184,6 +185,14 @@ class RnntEngine:
         self._chk(self.lib.rnnt_encoder_chunk(self.ctx, fbank_ptr, chunk_frames, offset, required_cache_size, ctypes.byref(t), stream),
                   "rnnt_encoder_chunk")
         return t.value
+
+    def decode_ragged(self, fbank_ptr, total_frames, lens, chunk_frames, stream=None):
+        """rnnt_decode_ragged: every stream over its own lens[b] frames (decode-script chunk loop), one call; returns encoder frames per stream."""
+        a = np.ascontiguousarray(lens, np.int32)
+        assert a.size == self.n_streams
+        fo = np.zeros(self.n_streams, np.int32)
+        self._chk(self.lib.rnnt_decode_ragged(self.ctx, fbank_ptr, total_frames, _np_ptr(a), chunk_frames, _np_ptr(fo), stream), "rnnt_decode_ragged")
+        return fo
 
     def encoder_chunks(self, fbank_ptr, total_frames, starts, lens, offsets, required, stream=None, greedy=False):
         a, b, c, d = (np.ascontiguousarray(v, np.int32) for v in (starts, lens, offsets, required))

@@ -508,17 +508,31 @@ class StreamingBatch:
         """Greedy loop of online_rnnt_decode.py:81-117 for a PADDED batch of utterances of different lengths (utils/utils.py:29-50
         pads them; online_rnnt_eval.py:86-94 decodes each with its own audio_lens): stream b is decoded over its own
         audio_lens[b] frames with its own chunk plan (tail-merge rule, < 7-frame skip), so its tokens equal its B = 1 result.
-        The context advances its streams in lock step, so the batch is run as LENGTH CLASSES: streams with equal lengths share
-        one whole-utterance call (same chunk plan), classes follow one another on the same context.  A batch of equal lengths is
-        one call; n different lengths are n calls -- per-stream masking inside one launch is not implemented."""
+        pipelined=True: ONE library call (rnnt_decode_ragged: per-stream chunk plans inside the layer-major launches) for every
+        utterance of at least two chunks; utterances that are a single chunk (< chunk_frames + max(16, chunk_frames) frames) and the
+        per-chunk form (pipelined=False) run as LENGTH CLASSES: streams of equal length share one whole-utterance call."""
         assert audios.is_cuda and audios.dtype == torch.float32 and audios.size(0) == self.n
         lens = [int(v) for v in (audio_lens.tolist() if hasattr(audio_lens, "tolist") else audio_lens)]
         assert len(lens) == self.n and max(lens) <= audios.size(1) and min(lens) >= 0
         out: List[Optional[List[int]]] = [None] * self.n
+        two_chunks = chunk_frames + max(16, chunk_frames)
+        done = set()
+        if pipelined and audios.is_contiguous():
+            ragged = [b for b in range(self.n) if lens[b] >= two_chunks or lens[b] < 7]
+            big = [lens[b] for b in ragged if lens[b] >= two_chunks]
+            if big and max(big) >= 2 * chunk_frames + max(16, chunk_frames):    # the longest one has at least three chunks
+                self.reset()
+                call_lens = [lens[b] if b in set(ragged) else 0 for b in range(self.n)]
+                s = _stream_ptr()
+                self.engine.decode_ragged(audios.data_ptr(), audios.size(1), call_lens, chunk_frames, s)
+                toks = self.engine.tokens(s)
+                for b in ragged:
+                    out[b] = toks[b]
+                done = set(ragged)
         n_all = self.n
         try:
-            for T_ in sorted(set(lens), reverse=True):
-                idx = [b for b in range(n_all) if lens[b] == T_]
+            for T_ in sorted({lens[b] for b in range(n_all) if b not in done}, reverse=True):
+                idx = [b for b in range(n_all) if lens[b] == T_ and b not in done]
                 if T_ < 7:                                   # shorter than the conv front-end's receptive field: skipped (:356-359)
                     for b in idx:
                         out[b] = []

@@ -131,6 +131,16 @@ int rnnt_get_tokens(rnnt_ctx* ctx, int32_t* counts_host, int32_t* tokens_host, v
 /* drop decoded frames from the encoder-frame buffer (keeps undecoded ones). */
 int rnnt_frames_consume(rnnt_ctx* ctx, void* stream);
 
+/* Greedy decode of a padded batch of whole utterances of DIFFERENT lengths in one call (utils/utils.py:29-50 pads a batch,
+ * online_rnnt_eval.py:86-94 decodes every utterance with its own audio_lens): stream b runs the decode script's chunk loop
+ * (online_rnnt_decode.py:81-117) over its own lens_host[b] frames of fbank_dev [n_streams, total_frames, 80]; tokens / counts are
+ * read with the usual getters and equal a B = 1 run of that utterance.  Needs freshly reset streams (rnnt_streams_reset) and leaves
+ * them finished (reset before the next call).  Utterances of fewer than 7 frames give no tokens; an utterance that is a single
+ * chunk (at least 7 but fewer than chunk_frames + max(16, chunk_frames) frames) is refused with RNNT_ERR_SHAPE -- run those through
+ * rnnt_encoder_chunks.  frames_out [n_streams] (optional, host): encoder frames per stream. */
+int rnnt_decode_ragged(rnnt_ctx* ctx, const float* fbank_dev, int32_t total_frames, const int32_t* lens_host, int32_t chunk_frames,
+                       int32_t* frames_out, void* stream);
+
 /* -- beam search: device half of _decode_chunk_beam_search (model/online_rnnt_model.py:419-503) -- */
 /* One encoder frame, all live hypotheses ("rows") of all streams at once.  For every row the library runs the
  * reference's greedy extension chain (<= n_steps evaluations: predictor step, joint, log_softmax, blank

@@ -627,6 +627,42 @@ def test_ragged_batch_equals_single_stream_references(np_state_dict, numerics):
     assert sb.decode_script_ragged(x.cuda().contiguous(), torch.tensor(lens), 16, pipelined=False) == got
 
 
+def test_ragged_batch_64_lengths_one_call(np_state_dict, numerics):
+    """64 utterances of 64 DISTINCT lengths (40 .. 1000 frames) in one padded batch: decode_script_ragged makes exactly ONE library
+    call (rnnt_decode_ragged: per-stream chunk plans, tail chunks and key windows inside the layer-major launches) and no
+    per-class call, and every stream's tokens equal its own B = 1 whole-utterance run; three streams are also checked against
+    the CPU oracle run on the unpadded utterance (utils/utils.py:29-50, online_rnnt_eval.py:86-94)."""
+    from oracle import rnnt_oracle as O
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    n = 64
+    rng = np.random.default_rng(5)
+    lens = sorted(rng.choice(np.arange(40, 1001), size=n, replace=False).tolist(), reverse=True)
+    lens[0], lens[-1] = 1000, 40
+    perm = rng.permutation(n)
+    lens = [lens[i] for i in perm]                                   # long and short utterances interleaved over the batch positions
+    full = torch.from_numpy(T.synth_fbank(n, 1000, seed=4321))
+    x = torch.zeros(n, 1000, 80)
+    for b in range(n):
+        x[b, :lens[b]] = full[b, :lens[b]]
+    xd = x.cuda().contiguous()
+    sb = StreamingBatch(np_state_dict(0), n, max_chunk_frames=48, max_cache_frames=256, max_enc_frames=256)
+    calls = {"ragged": 0, "uniform": 0}
+    orig_r, orig_u = sb.engine.decode_ragged, sb.engine.encoder_chunks
+    sb.engine.decode_ragged = lambda *a, **k: (calls.__setitem__("ragged", calls["ragged"] + 1), orig_r(*a, **k))[1]
+    sb.engine.encoder_chunks = lambda *a, **k: (calls.__setitem__("uniform", calls["uniform"] + 1), orig_u(*a, **k))[1]
+    got = sb.decode_script_ragged(xd, torch.tensor(lens), 16)
+    assert calls == {"ragged": 1, "uniform": 0}
+    assert sb.decode_script_ragged(xd, torch.tensor(lens), 16) == got          # reproducible
+    one = StreamingBatch(np_state_dict(0), 1, max_chunk_frames=48, max_cache_frames=256, max_enc_frames=256)
+    for b in range(n):
+        want = one.decode_script(xd[b:b + 1, :lens[b]].contiguous(), 16, pipelined=True)[0]
+        assert got[b] == want, (b, lens[b], len(got[b]), len(want))
+    sd = O.to_torch_sd(np_state_dict(0))
+    for b in (int(np.argmax(lens)), int(np.argmin(lens)), 7):
+        want, _, _ = O.decode_script_greedy(sd, x[b:b + 1, :lens[b]], 16)
+        assert got[b] == want, (b, lens[b])
+
+
 @pytest.mark.parametrize("seed", ["0", "1", "0_padded"])
 def test_prefix_beam_search_matches_reference(seed, np_state_dict, numerics):
     """WeNet prefix beam search (CTC-fused, one symbol per frame, log_add prefix merge) on the full-context encoder
