@@ -481,54 +481,16 @@ def main():
                            "exchange_bytes_per_symbol_per_part": 8 * (320 + 8) if multi else 0,
                            "bound": "dependent chain of the slowest stream (latency), not bandwidth"}
     # ---- top-2 logit margins of every greedy decision of the batch (a token flip must be attributable) ----------------------------
-    # Teacher-forced replay in float64 torch on the GPU: the headline mode's encoder frames, the emitted tokens' predictor states
-    # (LSTM recurrence over each stream's own tokens), then the greedy walk (online_rnnt_model.py:193-220) evaluating
-    # joint(enc[t], pred[u]) at every cell it visits.  The minimum-margin stream joins the CPU-baseline sample below.
+    # Teacher-forced replay in float64 torch on the GPU (ctc_vr_amd.testing.greedy_margins) on the headline mode's encoder frames.
+    # The minimum-margin stream joins the CPU-baseline sample below.
     def margin_report():
         sb.reset()
         sb.engine.encoder_chunks(x.data_ptr(), args.frames, plan_args[0], plan_args[1], plan_args[2], plan_args[2], cs, greedy=False)
-        enc = torch.from_numpy(sb.engine.enc_frames(cs)).to(dev, torch.float64)                      # [B, F, 256]
-        W = {k: torch.from_numpy(np.asarray(v, np.float32)).to(dev, torch.float64) for k, v in sd_np.items() if k.startswith(("predictor.", "joint."))}
-        F_ = enc.size(1)
-        nmax = max(len(t) for t in toks)
-        tk = torch.full((B, nmax + 1), T.BLANK, dtype=torch.long, device=dev)                         # input token of predictor step u: blank, then the emitted tokens
-        for b, t in enumerate(toks):
-            if t:
-                tk[b, 1:len(t) + 1] = torch.tensor(t, device=dev)
-        h = torch.zeros(B, 256, dtype=torch.float64, device=dev); c = torch.zeros_like(h)
-        P = torch.empty(B, nmax + 1, 256, dtype=torch.float64, device=dev)
-        bias = W["predictor.rnn.bias_ih_l0"] + W["predictor.rnn.bias_hh_l0"]
-        for u in range(nmax + 1):                                                                      # predictor.forward_step (predictor.py:185-210)
-            g = W["predictor.embed.weight"][tk[:, u]] @ W["predictor.rnn.weight_ih_l0"].T + h @ W["predictor.rnn.weight_hh_l0"].T + bias
-            i_, f_, g_, o_ = g.chunk(4, dim=1)
-            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
-            h = torch.sigmoid(o_) * torch.tanh(c)
-            P[:, u] = (h @ W["predictor.projection.weight"].T + W["predictor.projection.bias"]) @ W["joint.pred_ffn.weight"].T + W["joint.pred_ffn.bias"]
-        E = enc @ W["joint.enc_ffn.weight"].T + W["joint.enc_ffn.bias"]
-        ar = torch.arange(B, device=dev)
-        t_ = torch.zeros(B, dtype=torch.long, device=dev); u_ = torch.zeros_like(t_); cnt = torch.zeros_like(t_)
-        mmin = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
-        replay_ok = torch.ones(B, dtype=torch.bool, device=dev)
-        nt = torch.tensor([len(t) for t in toks], device=dev)
-        for _ in range(F_ + nmax + 2):
-            act = t_ < F_
-            if not bool(act.any()):
-                break
-            lg = torch.tanh(E[ar, t_.clamp(max=F_ - 1)] + P[ar, u_.clamp(max=nmax)]) @ W["joint.ffn_out.weight"].T + W["joint.ffn_out.bias"]
-            top = lg.topk(2, dim=1)
-            k = top.indices[:, 0]
-            mmin = torch.where(act, torch.minimum(mmin, top.values[:, 0] - top.values[:, 1]), mmin)
-            emit = act & (k != T.BLANK)
-            replay_ok &= ~emit | ((u_ < nt) & (tk[ar, (u_ + 1).clamp(max=nmax)] == k))                  # the replay emits the GPU's tokens
-            u_ = u_ + emit.long(); cnt = cnt + emit.long()
-            adv = act & ((k == T.BLANK) | (cnt >= 10))
-            t_ = t_ + adv.long(); cnt = torch.where(adv, torch.zeros_like(cnt), cnt)
-        replay_ok &= u_ == nt
-        mm = mmin.cpu().numpy()
+        mm, replay_ok = T.greedy_margins(sd_np, sb.engine.enc_frames(cs), toks, T.BLANK, dev)
         order = np.argsort(mm)
         return {"definition": "top-1 minus top-2 joint logit at every cell the greedy walk visits, float64 torch replay on the headline mode's encoder frames (teacher-forced predictor)",
                 "min": float(mm.min()), "min_stream": int(order[0]), "five_smallest": [{"stream": int(b), "margin": float(mm[b])} for b in order[:5]],
-                "median_over_streams": float(np.median(mm)), "replay_reproduces_gpu_tokens_streams": int(replay_ok.sum().item()), "streams": B}
+                "median_over_streams": float(np.median(mm)), "replay_reproduces_gpu_tokens_streams": int(replay_ok.sum()), "streams": B}
     margins = margin_report()
     out["top2_margins"] = margins
 

@@ -350,3 +350,257 @@ __global__ __launch_bounds__(256) void rel_attention_lm_mfma(LmAttnP P) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// rel_attention_lm_bf<NSPLIT,F16>: rel_attention_lm_mfma with the three contractions on v_mfma_f32_16x16x32_{bf16,f16} (round 3).
+// The f32 matrix instruction runs at 1/16 of the 16-bit rate: K = 64 of one 16 x 16 score tile costs 16 x 32 = 512 cycles there
+// and 2 k-steps x 3 products x 16 = 96 cycles here (x = hi + lo, a_lo b_hi + a_hi b_lo + a_hi b_hi, f32 accumulate: the split
+// modes' error model, ~1e-5 relative on a score).  Same block / row tables, same phases (A scores, B softmax in f32, C PV), same
+// wave roles as the f32 kernel; what changes is the operand path:
+//   * K and the positional rows are staged as 16-bit plane images [row][64 d] (128-byte rows, 16-byte chunk c of row r at chunk
+//     c ^ ((r >> 1) & 7): the 16 lanes one ds_read_b128 lane group serves hit 16 distinct slots), split while they are staged;
+//   * V is staged TRANSPOSED, [d][64 keys], because the PV product sums over keys and an MFMA operand is k-contiguous per lane:
+//     a thread loads one 4-float piece of four consecutive keys and writes, per d, the four keys' halves as one 8-byte store;
+//   * (Q + u), (Q + v) are split once per workgroup into operand registers; the probabilities are split when phase C reads them.
+// Softmax statistics, rescaling and the output stay f32.  grid = (B*H, n_blocks), block = 256, dynamic LDS = LMB_LDS bytes.
+// ------------------------------------------------------------------------------------------------
+#define LMB_LDS (4 * 8192 + 2 * 10240 + (32 * LM2_LD + 32 * LM2_GLD + 64) * 4)
+__device__ __forceinline__ int lmb_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <int NSPLIT, bool F16>
+__global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
+    constexpr bool LO = NSPLIT == 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lmb_smem[];
+    unsigned char* Kh = lmb_smem;                       // [64 keys][64 d] 16-bit, hi plane
+    unsigned char* Kl = Kh + 8192;
+    unsigned char* Ph = Kl + 8192;                      // [80 positional rows][64 d]
+    unsigned char* Pl = Ph + 10240;
+    unsigned char* Vh = Pl + 10240;                     // [64 d][64 keys] (transposed)
+    unsigned char* Vl = Vh + 8192;
+    float* Sx = reinterpret_cast<float*>(Vl + 8192);    // [32][68]  matrix_ac scores, then probabilities
+    float* Gx = Sx + 32 * LM2_LD;                       // [32][84]  (Q + v) P^T over the tile's 80 positional rows
+    float* al = Gx + 32 * LM2_GLD;                      // [32] rescale factor of the tile, then 1 / sum
+    const int b = blockIdx.x / RNNT_H, h = blockIdx.x % RNNT_H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int qt = wave & 1, hf = wave >> 1;
+    const LmBlock* __restrict__ blk = P.blocks + (P.per_stream ? (long long)b * gridDim.y : 0) + blockIdx.y;
+    const int amin = ldgi(&blk->amin), amax = ldgi(&blk->amax), pmin = ldgi(&blk->pmin);
+    int s_ks[8], s_ke[8], s_prel[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const LmRow* rw = &blk->r[8 * wave + j];
+        s_ks[j] = 0; s_ke[j] = 0; s_prel[j] = 0;
+        if (ldgi(&rw->f) >= 0) {
+            s_ks[j] = ldgi(&rw->ks); s_ke[j] = ldgi(&rw->ke);
+            if (P.klen) s_ke[j] = min(s_ke[j], s_ks[j] + ldgi(P.klen + b));
+            s_prel[j] = ldgi(&rw->pshift) - pmin;
+        }
+    }
+    // contraction role: this lane's query row 16*qt + i, d = 32 s + 8 kq .. + 8 of k-step s: (Q + u) and (Q + v) as operand planes
+    const int my_f = ldgi(&blk->r[16 * qt + i].f);
+    uint4 quh[2], qul[2], qvh[2], qvl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int d = 32 * s + 8 * kq;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+        if (my_f >= 0) {
+            const float* qp = P.q + ((long long)b * P.F + my_f) * RNNT_D + h * RNNT_DK + d;
+            q0 = ldg4(qp); q1 = ldg4(qp + 4);
+        }
+        const float4 u0 = ldg4(P.bias_u + h * RNNT_DK + d), u1 = ldg4(P.bias_u + h * RNNT_DK + d + 4);
+        const float4 v0 = ldg4(P.bias_v + h * RNNT_DK + d), v1 = ldg4(P.bias_v + h * RNNT_DK + d + 4);
+        split8_16<F16, LO>(make_float4(q0.x + u0.x, q0.y + u0.y, q0.z + u0.z, q0.w + u0.w), make_float4(q1.x + u1.x, q1.y + u1.y, q1.z + u1.z, q1.w + u1.w), quh[s], qul[s]);
+        split8_16<F16, LO>(make_float4(q0.x + v0.x, q0.y + v0.y, q0.z + v0.z, q0.w + v0.w), make_float4(q1.x + v1.x, q1.y + v1.y, q1.z + v1.z, q1.w + v1.w), qvh[s], qvl[s]);
+    }
+    f32x4_ o[2];
+    o[0] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    o[1] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    float mrun[8], lrun[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mrun[j] = -INFINITY; lrun[j] = 0.f; }
+    const float* kbase = P.kc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
+    const float* vbase = P.vc + (long long)b * P.kv_stride * RNNT_D + h * RNNT_DK;
+    const float* pbase = P.ptab + h * RNNT_DK;
+    // staging roles.  K / positional rows: 8-float chunk c8 of row r, e = tid + 256 j -> (r = e >> 3, c8 = e & 7); V: the 4-float piece
+    // c4 of the four keys 4 kg .. 4 kg + 3.  The NEXT tile's loads are issued as soon as this tile's rows are in LDS.
+    const int kg = tid >> 4, c4 = tid & 15;
+    float4 rk[2][2], rp[3][2], rv[4];
+    auto tile_load = [&](int a0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j, r = e >> 3, c8 = e & 7;
+            rk[j][0] = make_float4(0.f, 0.f, 0.f, 0.f); rk[j][1] = rk[j][0];
+            if (a0 + r < amax) { const float* p_ = kbase + (long long)(a0 + r) * RNNT_D + 8 * c8; rk[j][0] = ldg4(p_); rk[j][1] = ldg4(p_ + 4); }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + 256 * j, r = e >> 3, c8 = e & 7;
+            const int pr = a0 + pmin + r;
+            rp[j][0] = make_float4(0.f, 0.f, 0.f, 0.f); rp[j][1] = rp[j][0];
+            if (e < 640 && pr >= 0 && pr < RNNT_PE_LEN) { const float* p_ = pbase + (long long)pr * RNNT_D + 8 * c8; rp[j][0] = ldg4(p_); rp[j][1] = ldg4(p_ + 4); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a0 + 4 * kg + j < amax) rv[j] = ldg4(vbase + (long long)(a0 + 4 * kg + j) * RNNT_D + 4 * c4);
+        }
+    };
+    auto put4 = [&](unsigned char* hi, unsigned char* lo, int off, float x0, float x1, float x2, float x3) {   // four values -> 8 bytes per plane
+        float r0, r1, r2, r3, d0, d1;
+        uint2 hv, lv;
+        hv.x = pack2_16<F16>(x0, x1, r0, r1);
+        hv.y = pack2_16<F16>(x2, x3, r2, r3);
+        *reinterpret_cast<uint2*>(hi + off) = hv;
+        if constexpr (LO) {
+            lv.x = pack2_16<F16>(r0, r1, d0, d1);
+            lv.y = pack2_16<F16>(r2, r3, d0, d1);
+            *reinterpret_cast<uint2*>(lo + off) = lv;
+        }
+    };
+    tile_load(amin);
+    for (int a0 = amin; a0 < amax; a0 += 64) {
+        __syncthreads();                                            // the previous tile's PV is done with the V image / Sx / al
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j, r = e >> 3, c8 = e & 7;
+            uint4 hv, lv;
+            split8_16<F16, LO>(rk[j][0], rk[j][1], hv, lv);
+            *reinterpret_cast<uint4*>(Kh + lmb_off(r, c8)) = hv;
+            if constexpr (LO) *reinterpret_cast<uint4*>(Kl + lmb_off(r, c8)) = lv;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + 256 * j, r = e >> 3, c8 = e & 7;
+            if (e < 640) {
+                uint4 hv, lv;
+                split8_16<F16, LO>(rp[j][0], rp[j][1], hv, lv);
+                *reinterpret_cast<uint4*>(Ph + lmb_off(r, c8)) = hv;
+                if constexpr (LO) *reinterpret_cast<uint4*>(Pl + lmb_off(r, c8)) = lv;
+            }
+        }
+        {   // V transposed: row d = 4 c4 + dd, keys 4 kg .. 4 kg + 3 = half (kg & 1) of 16-byte chunk kg >> 1
+            const int vo = (kg & 1) * 8;
+            put4(Vh, Vl, lmb_off(4 * c4 + 0, kg >> 1) + vo, rv[0].x, rv[1].x, rv[2].x, rv[3].x);
+            put4(Vh, Vl, lmb_off(4 * c4 + 1, kg >> 1) + vo, rv[0].y, rv[1].y, rv[2].y, rv[3].y);
+            put4(Vh, Vl, lmb_off(4 * c4 + 2, kg >> 1) + vo, rv[0].z, rv[1].z, rv[2].z, rv[3].z);
+            put4(Vh, Vl, lmb_off(4 * c4 + 3, kg >> 1) + vo, rv[0].w, rv[1].w, rv[2].w, rv[3].w);
+        }
+        __syncthreads();
+        if (a0 + 64 < amax) tile_load(a0 + 64);
+        // ---- A: matrix_ac tiles and G tiles of this wave's query tile ------------------------------------------------------------
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kt = 2 * hf + kk;
+            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = lmb_off(16 * kt + i, kq + 4 * s);
+                const uint4 kh = *reinterpret_cast<const uint4*>(Kh + off);
+                if constexpr (LO) {
+                    const uint4 kl = *reinterpret_cast<const uint4*>(Kl + off);
+                    acc = mfma16_<F16>(qul[s], kh, acc);
+                    acc = mfma16_<F16>(quh[s], kl, acc);
+                }
+                acc = mfma16_<F16>(quh[s], kh, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Sx[(16 * qt + 4 * kq + r) * LM2_LD + 16 * kt + i] = acc[r];
+        }
+        for (int gt = (hf ? 3 : 0); gt < (hf ? 5 : 3); ++gt) {
+            f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = lmb_off(16 * gt + i, kq + 4 * s);
+                const uint4 ph = *reinterpret_cast<const uint4*>(Ph + off);
+                if constexpr (LO) {
+                    const uint4 pl = *reinterpret_cast<const uint4*>(Pl + off);
+                    acc = mfma16_<F16>(qvl[s], ph, acc);
+                    acc = mfma16_<F16>(qvh[s], pl, acc);
+                }
+                acc = mfma16_<F16>(qvh[s], ph, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gx[(16 * qt + 4 * kq + r) * LM2_GLD + 16 * gt + i] = acc[r];
+        }
+        __syncthreads();
+        // ---- B: softmax of query slots 8*wave .. +7, lane = key (f32, as in rel_attention_lm_mfma) -----------------------------------
+        {
+            float sc[8], mx[8], pe_[8], sm[8];
+            bool live[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) live[j] = a0 < s_ke[j] && a0 + 64 > s_ks[j];   // wave-uniform
+            const int a = a0 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int qs = 8 * wave + j;
+                const bool valid = live[j] && a >= s_ks[j] && a < s_ke[j];
+                sc[j] = valid ? (Sx[qs * LM2_LD + lane] + Gx[qs * LM2_GLD + lane + s_prel[j]]) * 0.125f : -INFINITY;
+                mx[j] = sc[j];
+            }
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], o_, 64));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float mnew = fmaxf(mrun[j], mx[j]);
+                pe_[j] = sc[j] > -INFINITY ? expf(sc[j] - mnew) : 0.f;
+                sm[j] = pe_[j];
+                mx[j] = live[j] ? expf(mrun[j] - mnew) : 1.0f;               // alpha (first live tile: exp(-inf) = 0)
+                if (live[j]) mrun[j] = mnew;
+            }
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm[j] += __shfl_xor(sm[j], o_, 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int qs = 8 * wave + j;
+                lrun[j] = lrun[j] * mx[j] + sm[j];
+                Sx[qs * LM2_LD + lane] = pe_[j];
+                if (lane == 0) al[qs] = mx[j];
+            }
+        }
+        __syncthreads();
+        // ---- C: O = alpha O + P V for d tiles 2*hf, 2*hf + 1; the probabilities of row 16 qt + i, keys 32 s + 8 kq .. + 8, split here ----
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a_ = al[16 * qt + 4 * kq + r];
+            o[0][r] *= a_;
+            o[1][r] *= a_;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float* pp = &Sx[(16 * qt + i) * LM2_LD + 32 * s + 8 * kq];
+            uint4 ph, pl;
+            split8_16<F16, LO>(*reinterpret_cast<const float4*>(pp), *reinterpret_cast<const float4*>(pp + 4), ph, pl);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                const int off = lmb_off(16 * (2 * hf + dd) + i, kq + 4 * s);
+                const uint4 vh = *reinterpret_cast<const uint4*>(Vh + off);
+                if constexpr (LO) {
+                    const uint4 vl = *reinterpret_cast<const uint4*>(Vl + off);
+                    o[dd] = mfma16_<F16>(pl, vh, o[dd]);
+                    o[dd] = mfma16_<F16>(ph, vl, o[dd]);
+                }
+                o[dd] = mfma16_<F16>(ph, vh, o[dd]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (lane == 0) al[8 * wave + j] = lrun[j] > 0.f ? 1.0f / lrun[j] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * qt + 4 * kq + r;                       // query row of accumulator register r
+        const int fr = ldgi(&blk->r[row].f);
+        if (fr >= 0) {
+            const long long m = (long long)b * P.F + fr;
+            const float li = al[row];
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) stg1(P.out + m * RNNT_D + h * RNNT_DK + 16 * (2 * hf + dd) + i, o[dd][r] * li);
+        }
+    }
+}

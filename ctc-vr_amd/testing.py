@@ -92,3 +92,60 @@ def synth_fbank(batch, frames, seed=1234):
     g = np.random.Generator(np.random.Philox(key=[seed, 0xFBA]))
     x = g.standard_normal((batch, frames, IDIM), dtype=np.float32) * np.float32(FBANK_STD) + np.float32(FBANK_MEAN)
     return np.clip(x, FBANK_MIN, FBANK_MAX).astype(np.float32)
+
+
+def greedy_margins(sd_np, enc_frames, tokens, blank=BLANK, device="cuda", n_steps=10):
+    """Top-2 logit margin of every decision of a greedy decode (a token flip must be attributable).
+
+    Teacher-forced replay in float64 torch: `enc_frames` [B, F, 256] are the encoder frames the decode ran on, `tokens` the emitted
+    tokens per stream; the predictor states come from the LSTM recurrence over each stream's own tokens
+    (wenet/transducer/predictor.py:185-210), then the greedy walk (model/online_rnnt_model.py:193-220) evaluates
+    joint(enc[t], pred[u]) at every cell it visits.  Returns (min margin per stream [B] float64 numpy, replay_ok [B] bool numpy:
+    the replay emitted exactly `tokens`)."""
+    import torch
+    B = len(tokens)
+    dev = torch.device(device)
+    enc = torch.as_tensor(np.asarray(enc_frames)).to(dev, torch.float64)
+    W = {k: torch.from_numpy(np.asarray(v, np.float32)).to(dev, torch.float64) for k, v in sd_np.items() if k.startswith(("predictor.", "joint."))}
+    F_ = enc.size(1)
+    nmax = max([len(t) for t in tokens] + [0])
+    tk = torch.full((B, nmax + 1), blank, dtype=torch.long, device=dev)       # input token of predictor step u: blank, then the emitted tokens
+    for b, t in enumerate(tokens):
+        if t:
+            tk[b, 1:len(t) + 1] = torch.tensor(t, device=dev)
+    h = torch.zeros(B, D, dtype=torch.float64, device=dev)
+    c = torch.zeros_like(h)
+    P = torch.empty(B, nmax + 1, D, dtype=torch.float64, device=dev)
+    bias = W["predictor.rnn.bias_ih_l0"] + W["predictor.rnn.bias_hh_l0"]
+    for u in range(nmax + 1):
+        g = W["predictor.embed.weight"][tk[:, u]] @ W["predictor.rnn.weight_ih_l0"].T + h @ W["predictor.rnn.weight_hh_l0"].T + bias
+        i_, f_, g_, o_ = g.chunk(4, dim=1)
+        c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+        h = torch.sigmoid(o_) * torch.tanh(c)
+        P[:, u] = (h @ W["predictor.projection.weight"].T + W["predictor.projection.bias"]) @ W["joint.pred_ffn.weight"].T + W["joint.pred_ffn.bias"]
+    E = enc @ W["joint.enc_ffn.weight"].T + W["joint.enc_ffn.bias"]
+    ar = torch.arange(B, device=dev)
+    t_ = torch.zeros(B, dtype=torch.long, device=dev)
+    u_ = torch.zeros_like(t_)
+    cnt = torch.zeros_like(t_)
+    mmin = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+    ok = torch.ones(B, dtype=torch.bool, device=dev)
+    nt = torch.tensor([len(t) for t in tokens], device=dev)
+    for _ in range(F_ + nmax + 2):
+        act = t_ < F_
+        if not bool(act.any()):
+            break
+        lg = torch.tanh(E[ar, t_.clamp(max=F_ - 1)] + P[ar, u_.clamp(max=nmax)]) @ W["joint.ffn_out.weight"].T + W["joint.ffn_out.bias"]
+        top = lg.topk(2, dim=1)
+        k = top.indices[:, 0]
+        mmin = torch.where(act, torch.minimum(mmin, top.values[:, 0] - top.values[:, 1]), mmin)
+        emit = act & (k != blank)
+        ok &= ~emit | ((u_ < nt) & (tk[ar, (u_ + 1).clamp(max=nmax)] == k))
+        u_ = u_ + emit.long()
+        cnt = cnt + emit.long()
+        adv = act & ((k == blank) | (cnt >= n_steps))
+        t_ = t_ + adv.long()
+        cnt = torch.where(adv, torch.zeros_like(cnt), cnt)
+    ok &= u_ == nt
+    return mmin.cpu().numpy(), ok.cpu().numpy()
+

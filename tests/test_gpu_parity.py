@@ -338,7 +338,26 @@ def test_full_size_properties(np_state_dict, numerics):
     sb = StreamingBatch(sd_np, B, max_chunk_frames=24, max_cache_frames=200, max_enc_frames=200, max_tokens=1900)
     pipelined = sb.decode_script(x, 16, pipelined=True)
     assert sb.decode_script(x, 16, pipelined=True) == pipelined                      # deterministic
-    assert sb.decode_script(x, 16, per_chunk_decode=True) == pipelined               # per-chunk API, same tokens
+    per_chunk = sb.decode_script(x, 16, per_chunk_decode=True)                       # per-chunk API
+    if numerics == "fp32":
+        assert per_chunk == pipelined                                                # exact-f32 mode: the two schedules share every product and its order
+    else:
+        # Split modes: the whole-utterance schedule runs attention on 16-bit split MFMAs, the per-chunk API on the exact-f32
+        # kernels, so the encoder frames differ at the split error (~1e-5) and a decision whose top-2 logits are closer than
+        # that may fall the other way.  Attributable, not arbitrary: tokens may differ ONLY on streams whose smallest top-2
+        # margin (float64 replay on the whole-utterance call's frames, ctc_vr_amd.testing.greedy_margins) is under MARGIN_TOL,
+        # and only on a few of the 64.
+        MARGIN_TOL = 1e-3
+        plan = T.chunk_plan(1000, 16)
+        offs = [4 * i for i in range(len(plan))]
+        sb.reset()
+        sb.engine.encoder_chunks(x.data_ptr(), 1000, [a for a, _ in plan], [b - a for a, b in plan], offs, offs, torch.cuda.current_stream().cuda_stream)
+        margins, replay_ok = T.greedy_margins(sd_np, sb.engine.enc_frames(torch.cuda.current_stream().cuda_stream), pipelined)
+        assert (replay_ok | (margins < 1e-4)).all()                                   # the float64 replay follows the f32 decoder except across a near-tie
+        differ = [b for b in range(B) if per_chunk[b] != pipelined[b]]
+        assert len(differ) <= 3, differ
+        for b in differ:
+            assert margins[b] < MARGIN_TOL, (b, margins[b])
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(7))
     permuted = sb.decode_script(x[perm.cuda()].contiguous(), 16, pipelined=True)
     for i in range(B):
