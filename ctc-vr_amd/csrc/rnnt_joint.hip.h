@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256, JR_WGS_PER_CU) void joint_lattice_rows(JointRP
     // Operand formation: every load of the tile in flight at once (128 registers: the accumulators are dead here), so the L2 round
     // trip -- and the wait behind the previous tile's stores -- is paid once per tile, not once per k-step.  (Issuing part of the
     // loads before the softmax arithmetic / the stores was tried: hipcc rotates the loop and keeps prologue loads alive across
-    // the k-loop, spilling 30+ registers.)
+    // the k-loop, spilling 30+ registers.  Interleaving the store burst with the next tile's loads and formation in four rounds --
+    // seven stores, two k-steps -- compiles clean at 256 registers and is slower: 418 vs 408 us split, 346 vs 281 us plain bf16.)
     auto form_a = [&](int tl) {
         const int am = min(tl * JR_ROWS + wave * 16 + i, (int)P.M - 1);   // M < 2^31 (host check)
         const int bt = am / P.U;                               // (b, t) row of e

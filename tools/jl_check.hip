@@ -1,9 +1,12 @@
 // Standalone check + timing of the joint lattice kernel joint_lattice_rows (rnnt_joint.hip.h) against a CPU double reference on
+// (JL_STREAM=1: also the vocabulary-tile-outer experiment of tools/jl_stream_experiment.hip.h; -DJS_ABLATE=bits, -DJS_RB=4|8)
 // sampled rows; B64 x T249 x U28 x V412.  Build variants: -DJR_STORE=0|1|2, -DJR_ABLATE=bits, -DJR_TRACE=1.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/jl_check tools/jl_check.hip && tools/jl_check [wgs_per_cu | -grid] [stagger] [B T U V]
 #include "../ctc-vr_amd/csrc/rnnt_kernels.hip.h"
+#include "jl_stream_experiment.hip.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -23,6 +26,27 @@ static float run_new(const JointRP& rp, int reps) {
     for (int r = 0; r < reps; ++r) {
         CK(hipMemsetAsync(g_counter, 0, 16, 0));
         hipLaunchKernelGGL((joint_lattice_rows<NS, F16, LSM>), grid, dim3(256), JR_LDS_ALLOC, 0, rp);
+    }
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / reps;
+}
+
+static float* g_dump = nullptr;
+template <int NS, bool F16, bool LSM>
+static float run_stream(const JointRP& rp, const unsigned char* wfs, int reps) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&joint_lattice_stream<NS, F16, LSM>), hipFuncAttributeMaxDynamicSharedMemorySize, JS_LDS_ALLOC(NS)));
+    JointSP sp; sp.e = rp.e; sp.p = rp.p; sp.wfrag = wfs; sp.bias = rp.bias; sp.out = rp.out; sp.dump = g_dump; sp.M = rp.M; sp.T = rp.T; sp.U = rp.U; sp.V = rp.V;
+    sp.ntiles = (int)((rp.M + JS_ROWS - 1) / JS_ROWS); sp.ntv = (rp.V + 15) / 16; sp.counter = g_counter;
+    const dim3 grid((unsigned)std::min(sp.ntiles, g_cus));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipMemsetAsync(g_counter, 0, 16, 0));
+    hipLaunchKernelGGL((joint_lattice_stream<NS, F16, LSM>), grid, dim3(1024), JS_LDS_ALLOC(NS), 0, sp);
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) {
+        CK(hipMemsetAsync(g_counter, 0, 16, 0));
+        hipLaunchKernelGGL((joint_lattice_stream<NS, F16, LSM>), grid, dim3(1024), JS_LDS_ALLOC(NS), 0, sp);
     }
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
@@ -60,6 +84,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bias, hb.data(), V * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL((pack_joint_w<false, true>), dim3((16 * JR_PIECES * 64 + 255) / 256), dim3(256), 0, 0, w, V, wf2);
     hipLaunchKernelGGL((pack_joint_w<false, false>), dim3((8 * JR_PIECES * 64 + 255) / 256), dim3(256), 0, 0, w, V, wf1);
+    unsigned char *ws2, *ws1;
+    const int ntv = (V + 15) / 16;
+    CK(hipMalloc(&ws2, (size_t)ntv * JS_SLOT(2))); CK(hipMalloc(&ws1, (size_t)ntv * JS_SLOT(1))); CK(hipMalloc(&g_dump, (size_t)JS_ROWS * V * 4));
+    hipLaunchKernelGGL((pack_joint_w_stream<false, true>), dim3((ntv * 16 * 64 + 255) / 256), dim3(256), 0, 0, w, V, ws2);
+    hipLaunchKernelGGL((pack_joint_w_stream<false, false>), dim3((ntv * 8 * 64 + 255) / 256), dim3(256), 0, 0, w, V, ws1);
     CK(hipDeviceSynchronize());
     JointRP rp; rp.e = es; rp.p = ps; rp.wfrag = wf2; rp.bias = bias; rp.out = out1; rp.M = M; rp.T = T; rp.U = U; rp.V = V; rp.ntiles = (int)((M + JR_ROWS - 1) / JR_ROWS); rp.counter = g_counter; rp.stagger = g_stagger;
     const double bytes = 4.0 * ((double)B * T * 256 + (double)B * U * 256) + 4.0 * (256.0 * V + V) + 4.0 * (double)M * V;
@@ -94,6 +123,23 @@ int main(int argc, char** argv) {
     BOTH(2, true, "bf16x3 log-softmax")
     BOTH(1, false, "bf16 logits")
     BOTH(1, true, "bf16 log-softmax")
+#define STREAM(NS, LSM, NAME)                                                                                         \
+    if (std::getenv("JL_STREAM")) {                                                                                    \
+        rp.wfrag = NS == 2 ? wf2 : wf1;                                                                               \
+        run_new<NS, false, LSM>(rp, 1);                                                                               \
+        CK(hipMemcpy(h0.data(), out1, h0.size() * 4, hipMemcpyDeviceToHost));                                         \
+        CK(hipMemset(out1, 0xee, (size_t)M * V * 4));                                                                 \
+        const float t_new = run_stream<NS, false, LSM>(rp, NS == 2 ? ws2 : ws1, 5);                                   \
+        printf("stream %s: %.1f us (%.2f TB/s, %.3f of 8 TB/s)\n", NAME, t_new, bytes / t_new / 1e6, bytes / t_new / 8e6); \
+        compare("stream " NAME, LSM, NS == 2);                                                                        \
+        double dm = 0; size_t nbad = 0;                                                                               \
+        for (size_t k = 0; k < h0.size(); ++k) { const double d = fabs((double)h0[k] - h1[k]); if (!(d <= 1e-3)) ++nbad; if (!(d <= dm)) dm = d; } \
+        printf("  stream vs rows kernel, all %zu values: max diff %.3g, %zu beyond 1e-3\n", h0.size(), dm, nbad);      \
+    }
+    STREAM(2, false, "bf16x3 logits")
+    STREAM(2, true, "bf16x3 log-softmax")
+    STREAM(1, false, "bf16 logits")
+    STREAM(1, true, "bf16 log-softmax")
 #if JR_TRACE
     {
         const char* nm[8] = {"mfma+lds+dma issue", "dma wait", "barrier", "epilogue math", "store issue", "operand formation", "total (last store issued)", "total (stores drained)"};
