@@ -26,41 +26,31 @@ struct AsBatch {
     int ng;
 };
 
-// Epilogue of one wave's (16*MT) x 64 accumulator block through LDS: straight from the MFMA C layout a lane owns one column of
-// four rows, i.e. 4-byte stores in 64-byte pieces, and the kernel is store-ISSUE bound (measured: 14.5 us of a 28 us launch for
-// 12032 x 256 outputs).  Each wave parks one 16 x 64 row tile at a time in its own 4.25 KiB of LDS and reads it back as
-// float4 per lane (16 lanes = one row's 256 contiguous bytes); bias / activation / residual / GLU are applied on the float4,
-// so every global access of the epilogue is 16 bytes per lane (8 for the halved GLU rows).  Row addressing = c_row_off.
-#define AS_SLD 68
+#define AS_SLD 68   // (row stride of the per-wave staging rows of the round-2 epilogue; still part of the LDS size formulas)
+// Epilogue of one wave's (16*MT) x (16*NTW) accumulator block.  Every contraction of this file runs with the MFMA operands
+// SWAPPED (A = weight fragment, B = row fragment; bitwise the same sums as the other order -- tools/gemm_check checksums): the tile
+// comes out transposed, i.e. a lane owns ONE row (16 mt + i) and four CONSECUTIVE columns (16 t + 4 q + 0..3), so bias,
+// activation, residual and GLU apply to the accumulator registers and every global access is 16 bytes per lane (8 for the halved
+// GLU rows) with no LDS staging; a wave instruction covers 16 rows x 64 bytes.  (Round 2 parked each row tile in per-wave LDS rows
+// and read it back as float4: gemm_as 51 -> 41 us on LN + w_1 + SiLU at M = 12032, 16.2 -> 13.5 us on a q/k/v-like launch.)
 template <int MT, int NTW = 4>
-__device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[MT][NTW], int m0, int n0, float* stage, int lane) {
-    constexpr int LPR = 4 * NTW, RPP = 64 / LPR;                   // lanes per row (float4 each), rows per read-back pass
-    constexpr int SLD = 16 * NTW + 4;                              // staging row stride in floats (68 for the 64-column form)
+__device__ __forceinline__ void as_epilogue_t(const GemmP& p, const f32x4_ (&acc)[MT][NTW], int m0, int n0, int lane) {
     const int i = lane & 15, q = lane >> 4;
     const int epi = p.epi;
-    const int c4 = (lane % LPR) * 4, n = n0 + c4;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) bias = ldg4(p.bias + n);
+    float4 bias[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bias[t] = p.bias ? ldg4(p.bias + n0 + 16 * t + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 16 * mt + i;
+        if (m >= p.M) continue;
+        const long long crow = c_row_off(p, m);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(4 * q + r) * SLD + 16 * t + i] = acc[mt][t][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int j = 0; j < 16 / RPP; ++j) {
-            const int rr = lane / LPR + RPP * j;
-            const int m = m0 + 16 * mt + rr;
-            float4 v = *reinterpret_cast<const float4*>(&stage[rr * SLD + c4]);
-            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            if (m >= p.M) continue;
-            const long long crow = c_row_off(p, m);
+        for (int t = 0; t < NTW; ++t) {
+            const int n = n0 + 16 * t + 4 * q;
+            float4 v = make_float4(acc[mt][t][0] + bias[t].x, acc[mt][t][1] + bias[t].y, acc[mt][t][2] + bias[t].z, acc[mt][t][3] + bias[t].w);
             if (epi == EPI_GLU) {                                   // (value, gate) interleaved columns -> n / 2
-                stg1(p.C + crow + (n >> 1), v.x * sigmoidf_(v.y));
-                stg1(p.C + crow + (n >> 1) + 1, v.z * sigmoidf_(v.w));
+                *reinterpret_cast<float2*>(p.C + crow + (n >> 1)) = make_float2(v.x * sigmoidf_(v.y), v.z * sigmoidf_(v.w));
                 continue;
             }
             if (epi == EPI_SILU) { v.x *= sigmoidf_(v.x); v.y *= sigmoidf_(v.y); v.z *= sigmoidf_(v.z); v.w *= sigmoidf_(v.w); }
@@ -72,8 +62,6 @@ __device__ __forceinline__ void as_epilogue(const GemmP& p, const f32x4_ (&acc)[
             }
             stg4(p.C + crow + n, v);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -92,7 +80,6 @@ __global__ __launch_bounds__(256) void gemm_as(AsBatch P) {
     const unsigned char* rowp[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rowp[mt] = as_op + (16 * mt + i) * ROWB;
-    float* estage = reinterpret_cast<float*>(as_op + U * R * ROWB) + wave * (16 * AS_SLD);   // this wave's epilogue staging rows
 
     // ---- A staging: rows bm0.. of phase kp -> operand image (LayerNorm prologue when set; K = 256 then) -------------------------
     auto stage = [&](int kp) {
@@ -197,10 +184,10 @@ __global__ __launch_bounds__(256) void gemm_as(AsBatch P) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (LO) {
-                    acc[mt][t] = mfma16_<F16>(al[mt], b[t * U], acc[mt][t]);
-                    acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U + 1], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(b[t * U], al[mt], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(b[t * U + 1], ah[mt], acc[mt][t]);
                 }
-                acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U], acc[mt][t]);
+                acc[mt][t] = mfma16_<F16>(b[t * U], ah[mt], acc[mt][t]);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -232,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_as(AsBatch P) {
                 mma(acc, b1, ks + 1);
             }
         }
-        as_epilogue<MT>(p0, acc, bm0, wave * 64, estage, lane);
+        as_epilogue_t<MT>(p0, acc, bm0, wave * 64, lane);
         return;
     }
     // ---- K = 256: the image is staged once; (matrix, column group) pairs of this wave one after the other --------------------------
@@ -258,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_as(AsBatch P) {
             mma(acc, b1, ks + 1);
         }
         AS_STAMP(3)
-        as_epilogue<MT>(P.g[gi], acc, bm0, grp * 64, estage, lane);
+        as_epilogue_t<MT>(P.g[gi], acc, bm0, grp * 64, lane);
         AS_STAMP(4)
         gi = ngi; grp = ngrp;
     }
@@ -314,7 +301,6 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     const int i = lane & 15, q = lane >> 4;
     const int bm0 = blockIdx.x * R;
     if (bm0 >= P.M) return;
-    float* estage = reinterpret_cast<float*>(ffn_smem + 2 * IMG) + wave * (16 * AS_SLD);
     float* fin = reinterpret_cast<float*>(ffn_smem);                            // [R][FFN_FLD] after the last contraction
     static_assert(R * FFN_FLD * 4 <= 2 * IMG + NW * 16 * AS_SLD * 4, "result rows must fit the operand images + staging rows");
     // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
@@ -416,10 +402,10 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (LO) {
-                    acc[mt][t] = mfma16_<F16>(al[mt], b[t * U], acc[mt][t]);
-                    acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U + 1], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(b[t * U], al[mt], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(b[t * U + 1], ah[mt], acc[mt][t]);
                 }
-                acc[mt][t] = mfma16_<F16>(ah[mt], b[t * U], acc[mt][t]);
+                acc[mt][t] = mfma16_<F16>(b[t * U], ah[mt], acc[mt][t]);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -475,36 +461,18 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             umma(hacc, b1, ks + KU, Xop);
         }
         {
-            // hidden columns c*256 + wave*64 .. +64 = silu(acc + b1) -> Hop (through the wave's staging rows: 8-float chunks)
-            constexpr int LPR = CW / 8, HRP = 64 / LPR;              // lanes per row (8 columns each), rows per pass
-            const int rr0 = lane / LPR, c8 = lane % LPR;
-            const float* bp = P.b1 + c * 256 + wave * CW + 8 * c8;
-            const float4 ba = ldg4(bp), bq = ldg4(bp + 4);
+            // hidden columns c*256 + wave*CW .. +CW = silu(acc + b1) -> Hop straight from the (transposed) C layout: a lane holds 4
+            // consecutive columns of one row = an 8-byte half chunk of each plane (39.8 -> 38.5 us against the round-2 staging round trip)
+            const float* bp = P.b1 + c * 256 + wave * CW + 4 * q;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int t = 0; t < NTW; ++t) {
+                const float4 bb = ldg4(bp + 16 * t);
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) estage[(4 * q + r) * AS_SLD + 16 * t + i] = hacc[mt][t][r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int ps = 0; ps < 16 / HRP; ++ps) {
-                    const int rr = rr0 + HRP * ps;
-                    float4 x0 = *reinterpret_cast<const float4*>(&estage[rr * AS_SLD + 8 * c8]);
-                    float4 x1 = *reinterpret_cast<const float4*>(&estage[rr * AS_SLD + 8 * c8 + 4]);
-                    x0.x += ba.x; x0.y += ba.y; x0.z += ba.z; x0.w += ba.w; x1.x += bq.x; x1.y += bq.y; x1.z += bq.z; x1.w += bq.w;
-                    x0.x *= sigmoidf_(x0.x); x0.y *= sigmoidf_(x0.y); x0.z *= sigmoidf_(x0.z); x0.w *= sigmoidf_(x0.w);
-                    x1.x *= sigmoidf_(x1.x); x1.y *= sigmoidf_(x1.y); x1.z *= sigmoidf_(x1.z); x1.w *= sigmoidf_(x1.w);
-                    uint4 h, l;
-                    split8_16<F16, LO>(x0, x1, h, l);
-                    const int off = op_off<NUM>(16 * mt + rr, wave * LPR + c8);
-                    *reinterpret_cast<uint4*>(Hop + off) = h;
-                    if constexpr (LO) *reinterpret_cast<uint4*>(Hop + R * ROWB + off) = l;
+                for (int mt = 0; mt < MT; ++mt) {
+                    float4 x = make_float4(hacc[mt][t][0] + bb.x, hacc[mt][t][1] + bb.y, hacc[mt][t][2] + bb.z, hacc[mt][t][3] + bb.w);
+                    x.x *= sigmoidf_(x.x); x.y *= sigmoidf_(x.y); x.z *= sigmoidf_(x.z); x.w *= sigmoidf_(x.w);
+                    op_store4<NUM>(Hop, R, 16 * mt + i, wave * CW + 16 * t + 4 * q, x);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();                                            // Hop complete
@@ -524,8 +492,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fin[(16 * mt + 4 * q + r) * FFN_FLD + wave * CW + 16 * t + i] = yacc[mt][t][r];
+            *reinterpret_cast<f32x4_*>(&fin[(16 * mt + i) * FFN_FLD + wave * CW + 16 * t + 4 * q]) = yacc[mt][t];
     __syncthreads();
     {
         const int l16 = tid & 15;
@@ -602,7 +569,6 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     if (P.n_tail > 0) {
         static_assert(R * FFN_FLD * 4 <= FFN_TIMG, "the tail image must start behind the result rows");
         const unsigned char* Top = ffn_smem + FFN_TIMG;
-        float* estage2 = reinterpret_cast<float*>(ffn_smem + FFN_TIMG + IMG) + wave * (16 * AS_SLD);
         // (matrix, CW-column group) pairs of this wave
         __syncthreads();                                            // tail image complete
         // (matrix, 64-column group) pairs of this wave, one after the other; the next pair's first unit is in flight across the epilogue
@@ -625,7 +591,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
                 else if (ngi < P.n_tail) bload(b0[0], P.twp[ngi], 8, ngrp * NTW, 0);
                 mma(hacc, b0[1], ks + 1, Top);
             }
-            as_epilogue<MT, NTW>(P.tg[gi], hacc, bm0, grp * CW, estage2, lane);
+            as_epilogue_t<MT, NTW>(P.tg[gi], hacc, bm0, grp * CW, lane);
             gi = ngi; grp = ngrp;
         }
     }
@@ -647,7 +613,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
     constexpr int U = C::PLANES, MT = 8, NTW = 16 / NW, NT = 64 * NW, AJ = 512 / NT;   // AJ: 8-float A chunks per thread and k-step
     __shared__ uint4 Ah[2][512];
     __shared__ uint4 Al[LO ? 2 : 1][LO ? 512 : 1];
-    __shared__ __attribute__((aligned(16))) float estage_all[NW * 16 * (16 * NTW + 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int bm0 = blockIdx.x * 128;
@@ -707,10 +672,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 if constexpr (LO) {
-                    acc[mt][t] = mfma16_<F16>(al, b[t * U], acc[mt][t]);
-                    acc[mt][t] = mfma16_<F16>(ah, b[t * U + 1], acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(b[t * U], al, acc[mt][t]);
+                    acc[mt][t] = mfma16_<F16>(b[t * U + 1], ah, acc[mt][t]);
                 }
-                acc[mt][t] = mfma16_<F16>(ah, b[t * U], acc[mt][t]);
+                acc[mt][t] = mfma16_<F16>(b[t * U], ah, acc[mt][t]);
             }
         }
     };
@@ -733,5 +698,5 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
             __syncthreads();
         }
     }
-    as_epilogue<MT, NTW>(p, acc, bm0, wave * 16 * NTW, estage_all + wave * (16 * (16 * NTW + 4)), lane);
+    as_epilogue_t<MT, NTW>(p, acc, bm0, wave * 16 * NTW, lane);
 }

@@ -245,9 +245,6 @@ int main() {
         printf("conv2-like: M=222528 N=256 K=2304\n");
         Prob p = make(222528, 256, 2304, false, EPI_RELU);
         auto r22 = run<2, 2>("<2,2>", p, 5);
-        auto r48 = run<4, 8>("<4,8>", p, 5);
-        auto r28 = run<2, 8>("<2,8>", p, 5);
-        auto r44 = run<4, 4>("<4,4>", p, 5);
         auto run_bw = [&](auto kern, int threads, const char* nm) {
             GemmBatch gb = desc(p);
             dim3 grid((p.M + 127) / 128);
@@ -266,7 +263,6 @@ int main() {
         };
         run_bw(gemm_bw<RNNT_NUM_BF16X3, 4>, 256, "gemm_bw<4>");
         run_bw(gemm_bw<RNNT_NUM_BF16X3, 8>, 512, "gemm_bw<8>");
-        printf("  <4,8> == <2,2>: %d, <2,8> == <2,2>: %d\n", (int)!memcmp(r48.data(), r22.data(), r22.size() * 4), (int)!memcmp(r28.data(), r22.data(), r22.size() * 4));
         return 0;
     }
     problem("ffn1 (LN + SiLU)", 12032, 1024, 256, true, EPI_SILU);
