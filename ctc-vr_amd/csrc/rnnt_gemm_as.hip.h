@@ -487,6 +487,13 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         __syncthreads();                                            // every wave is done with Hop (after the last slice: with Xop too)
     }
     }
+    // the tail (units of this wave: see there); the first matrix's first weight
+    // unit is requested here, so it is in flight across the result-row phase (the weight stream would idle there otherwise)
+    auto tload = [&](uint4 (&b)[KU][NTW * U], const uint4* Wp, int ct0, int ks0) {
+#pragma unroll
+        for (int k = 0; k < KU; ++k) bload(b[k], Wp, 8, ct0, ks0 + k);
+    };
+    if (P.n_tail > 0) { tload(b0, P.twp[0], wave * NTW, 0); tload(b1, P.twp[0], wave * NTW, KU); }   // (both buffers: a load issued behind the Y stores waits for their acknowledgement)
     // ---- result rows through LDS: residual, optional norm_final, float4 stores -------------------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -494,6 +501,8 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         for (int t = 0; t < NTW; ++t)
             *reinterpret_cast<f32x4_*>(&fin[(16 * mt + i) * FFN_FLD + wave * CW + 16 * t + 4 * q]) = yacc[mt][t];
     __syncthreads();
+    constexpr int NPS = (R + 4 * NW - 1) / (4 * NW);            // result-row passes (4 NW rows each)
+    float4 ykeep[NPS][4];
     {
         const int l16 = tid & 15;
         float4 b2v[4], gv[4], bv[4];
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             if (P.lno_g) { gv[j] = ldg4(P.lno_g + 4 * (l16 + 16 * j)); bv[j] = ldg4(P.lno_b + 4 * (l16 + 16 * j)); }
         }
 #pragma unroll
-        for (int ps = 0; ps < (R + 4 * NW - 1) / (4 * NW); ++ps) {
+        for (int ps = 0; ps < NPS; ++ps) {
             const int row = (tid >> 4) + 4 * NW * ps, m = bm0 + row;
             if (row >= R) continue;
             const long long go = (long long)min(m, P.M - 1) * RNNT_D;
@@ -537,7 +546,10 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
                     v[j].z = v[j].z * rstd * gv[j].z + bv[j].z; v[j].w = v[j].w * rstd * gv[j].w + bv[j].w;
                 }
             }
-            if (m < P.M) {
+            if (P.n_tail > 0) {                                     // with a tail the rows are stored behind its contractions (see there)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ykeep[ps][j] = v[j];
+            } else if (m < P.M) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) stg4(P.Y + go + 4 * (l16 + 16 * j), v[j]);
             }
@@ -569,30 +581,49 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     if (P.n_tail > 0) {
         static_assert(R * FFN_FLD * 4 <= FFN_TIMG, "the tail image must start behind the result rows");
         const unsigned char* Top = ffn_smem + FFN_TIMG;
-        // (matrix, CW-column group) pairs of this wave
         __syncthreads();                                            // tail image complete
-        // (matrix, 64-column group) pairs of this wave, one after the other; the next pair's first unit is in flight across the epilogue
-        int gi = 0, grp = wave;
-        while (gi < P.n_tail && grp * CW >= P.tg[gi].N) { ++gi; grp = wave; }
-        if (gi < P.n_tail) bload(b0[0], P.twp[gi], 8, grp * NTW, 0);
-        while (gi < P.n_tail) {
-            int ngi = gi, ngrp = grp + NW;
-            while (ngi < P.n_tail && ngrp * CW >= P.tg[ngi].N) { ++ngi; ngrp = wave; }
+        // All contractions first, all output stores last: vmcnt is one in-order counter for loads and stores, so a weight load
+        // issued behind an epilogue's stores is not usable before those stores are acknowledged (measured: ~2.5 us per
+        // epilogue in the critical path of every wave).  The result rows wait in registers for the same reason.
+        // Units of this wave: (matrix g, 256-column half h) -> columns (h * NW + wave) * CW .. + CW of matrix g; at most three
+        // (linear_q / k / v: 3 x 256 columns; pointwise_conv1: 1 x 512).
+        f32x4_ tacc[3][MT][NTW];
+        int ug = 0, uh = 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (ug >= P.n_tail) break;
+            int ng = ug, nh = uh + 1;
+            if (nh * 256 >= P.tg[ug].N) { ++ng; nh = 0; }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) hacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
-            const uint4* Wp = P.twp[gi];
+                for (int t = 0; t < NTW; ++t) tacc[u][mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+            const uint4* Wp = P.twp[ug];
+            const int ct0 = (uh * NW + wave) * NTW;
 #pragma unroll
-            for (int ks = 0; ks < 8; ks += 2) {
-                bload(b0[1], Wp, 8, grp * NTW, ks + 1);
-                mma(hacc, b0[0], ks, Top);
-                if (ks + 2 < 8) bload(b0[0], Wp, 8, grp * NTW, ks + 2);
-                else if (ngi < P.n_tail) bload(b0[0], P.twp[ngi], 8, ngrp * NTW, 0);
-                mma(hacc, b0[1], ks + 1, Top);
+            for (int ks = 0; ks < 8; ks += 2 * KU) {            // the FFN's unit pipeline: one unit consumed, the next in flight
+                if (u > 0 || ks > 0) tload(b1, Wp, ct0, ks + KU);
+                umma(tacc[u], b0, ks, Top);
+                if (ks + 2 * KU < 8) tload(b0, Wp, ct0, ks + 2 * KU);
+                else if (ng < P.n_tail) tload(b0, P.twp[ng], (nh * NW + wave) * NTW, 0);
+                umma(tacc[u], b1, ks + KU, Top);
             }
-            as_epilogue_t<MT, NTW>(P.tg[gi], hacc, bm0, grp * CW, lane);
-            gi = ngi; grp = ngrp;
+            ug = ng; uh = nh;
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {                          // the result rows kept from the result-row phase
+            const int row = (tid >> 4) + 4 * NW * ps, m = bm0 + row;
+            if (row < R && m < P.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) stg4(P.Y + (long long)m * RNNT_D + 4 * ((tid & 15) + 16 * j), ykeep[ps][j]);
+            }
+        }
+        ug = 0; uh = 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (ug >= P.n_tail) break;
+            as_epilogue_t<MT, NTW>(P.tg[ug], tacc[u], bm0, (uh * NW + wave) * CW, lane);
+            if (++uh * 256 >= P.tg[ug].N) { ++ug; uh = 0; }
         }
     }
 }

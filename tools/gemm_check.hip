@@ -182,6 +182,19 @@ static void problem_ffn(int M, bool lno) {
     hipLaunchKernelGGL((pack_frag<RNNT_NUM_BF16X3>), dim3(1024), dim3(256), 0, 0, W2, 256, 1024, 1024, w2p);
     CK(hipDeviceSynchronize());
     FfnP P{X, Y, g, b, w1p, w2p, b1, b2, lno ? go : nullptr, lno ? bo : nullptr, 0.5f, M};
+    const bool tail = getenv("GC_TAIL") != nullptr;   // + LN and three K = 256, N = 256 contractions from the result rows (the macaron FFN -> q/k/v launch); timing only
+    if (tail) {
+        P.n_tail = 3; P.lnt_g = g; P.lnt_b = b;
+        for (int k = 0; k < 3; ++k) {
+            float* Wt; uint4* wtp; float* Ct;
+            CK(hipMalloc(&Wt, 256 * 256 * 4)); CK(hipMalloc(&wtp, 256 * 256 * 4)); CK(hipMalloc(&Ct, hX.size() * 4));
+            CK(hipMemcpy(Wt, W1 + k * 65536, 256 * 256 * 4, hipMemcpyDeviceToDevice));
+            hipLaunchKernelGGL((pack_frag<RNNT_NUM_BF16X3>), dim3(256), dim3(256), 0, 0, Wt, 256, 256, 256, wtp);
+            GemmP t{}; t.C = Ct; t.bias = b2; t.M = M; t.N = 256; t.K = 256; t.c_plain = 1; t.c_s1 = 256; t.epi = EPI_BIAS;
+            P.tg[k] = t; P.twp[k] = wtp;
+        }
+        CK(hipDeviceSynchronize());
+    }
 #ifndef FFN_MT
 #define FFN_MT 3
 #endif
@@ -190,7 +203,7 @@ static void problem_ffn(int M, bool lno) {
 #define FFN_NW 4
 #endif
     constexpr int NW = FFN_NW;
-    const size_t lds = (size_t)2 * 2 * 16 * MT * 512 + NW * 16 * AS_SLD * 4;
+    const size_t lds = tail ? FFN_LDS(RNNT_NUM_BF16X3, NW) : (size_t)2 * 2 * 16 * MT * 512 + NW * 16 * AS_SLD * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_as<RNNT_NUM_BF16X3, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((M + 16 * MT - 1) / (16 * MT));
     std::vector<float> first(hX.size()), out(hX.size());
@@ -208,6 +221,25 @@ static void problem_ffn(int M, bool lno) {
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / 20;
+    if (getenv("GC_ROTATE")) {   // the same launch over 12 different copies of the weights and 2 activation buffers (as 12 layers would)
+        uint4 *w1r[12], *w2r[12]; float* Xr[2];
+        for (int k = 0; k < 12; ++k) {
+            CK(hipMalloc(&w1r[k], hW1.size() * 4)); CK(hipMalloc(&w2r[k], hW2.size() * 4));
+            CK(hipMemcpy(w1r[k], w1p, hW1.size() * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(w2r[k], w2p, hW2.size() * 4, hipMemcpyDeviceToDevice));
+        }
+        for (int k = 0; k < 2; ++k) { CK(hipMalloc(&Xr[k], hX.size() * 4)); CK(hipMemcpy(Xr[k], X, hX.size() * 4, hipMemcpyDeviceToDevice)); }
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < 24; ++r) {
+            FfnP Q = P; Q.w1p = w1r[r % 12]; Q.w2p = w2r[r % 12]; Q.X = Xr[r & 1]; Q.Y = Xr[(r & 1) ^ 1];
+            hipLaunchKernelGGL((ffn_as<RNNT_NUM_BF16X3, MT, NW>), grid, dim3(64 * NW), lds, 0, Q);
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("             rotating over 12 weight copies: %.1f us per launch\n", ms * 1e3 / 24);
+        for (int k = 0; k < 12; ++k) { hipFree(w1r[k]); hipFree(w2r[k]); }
+        for (int k = 0; k < 2; ++k) hipFree(Xr[k]);
+    }
     double worst = 0;
     for (int s = 0; s < 16; ++s) {
         const int m = (int)(((long long)s * 7919 + (s == 15 ? M - 1 : 0)) % M);
