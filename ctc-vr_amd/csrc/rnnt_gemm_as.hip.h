@@ -20,13 +20,15 @@ __device__ long long as_trace[4096 * 8];
 #define AS_STAMP(k_)
 #endif
 #define AS_MT_ 3
+#ifndef FFN_ABL2
+#define FFN_ABL2 0   // tools/gemm_check timing experiments only: 1 no weight loads, 2 no MFMAs / A-fragment reads
+#endif
 struct AsBatch {
     GemmP g[3];
     const uint4* wp[3];     // fragment-major packed weights (pack_frag) of g[i].W
     int ng;
 };
 
-#define AS_SLD 68   // (row stride of the per-wave staging rows of the round-2 epilogue; still part of the LDS size formulas)
 // Epilogue of one wave's (16*MT) x (16*NTW) accumulator block.  Every contraction of this file runs with the MFMA operands
 // SWAPPED (A = weight fragment, B = row fragment; bitwise the same sums as the other order -- tools/gemm_check checksums): the tile
 // comes out transposed, i.e. a lane owns ONE row (16 mt + i) and four CONSECUTIVE columns (16 t + 4 q + 0..3), so bias,
@@ -285,7 +287,9 @@ struct FfnP {
 #ifndef FFN_KU
 #define FFN_KU 2
 #endif
-#define FFN_LDS(NUM_, NW_) ((size_t)FFN_TIMG + (size_t)FuseCfg<NUM_>::PLANES * 16 * AS_MT_ * FuseCfg<NUM_>::ROWB + (NW_) * 16 * AS_SLD * 4)
+
+// [Xop | Hop] (2 images), overlaid by the result rows [R][FFN_FLD] and, behind those, the tail's operand image
+#define FFN_LDS(NUM_, NW_) ((size_t)FFN_TIMG + (size_t)FuseCfg<NUM_>::PLANES * 16 * AS_MT_ * FuseCfg<NUM_>::ROWB)
 // NW waves per workgroup (4 or 8): every wave owns 256 / NW of the 256 output columns of a contraction (NTW = 16 / NW column
 // tiles).  NW = 8 puts two waves on every SIMD, so one wave's waits on weight fragments hide under the other's MFMAs.
 template <int NUM, int MT, int NW = 4>
@@ -302,14 +306,14 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     const int bm0 = blockIdx.x * R;
     if (bm0 >= P.M) return;
     float* fin = reinterpret_cast<float*>(ffn_smem);                            // [R][FFN_FLD] after the last contraction
-    static_assert(R * FFN_FLD * 4 <= 2 * IMG + NW * 16 * AS_SLD * 4, "result rows must fit the operand images + staging rows");
+    static_assert(R * FFN_FLD * 4 <= FFN_TIMG && 2 * IMG <= FFN_TIMG + IMG, "result rows / both images must fit FFN_LDS");
     // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
     if (P.A0) {
-        constexpr int CJ = R * 32 / NT;                            // 8-float chunks per thread
+        constexpr int CJ = (R * 32 + NT - 1) / NT;                 // 8-float chunks per thread
         float4 va[CJ], vb[CJ];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-            const int e = tid + NT * j, r = e >> 5, c = e & 31;
+            const int e = min(tid + NT * j, R * 32 - 1), r = e >> 5, c = e & 31;
             const float* ap = P.A0 + (long long)min(bm0 + r, P.M - 1) * RNNT_D + 8 * c;
             va[j] = ldg4(ap);
             vb[j] = ldg4(ap + 4);
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int e = tid + NT * j, r = e >> 5, c = e & 31;
+            if (e >= R * 32) continue;
             uint4 h, l;
             split8_16<F16, LO>(va[j], vb[j], h, l);
             const int off = op_off<NUM>(r, c);
@@ -376,6 +381,10 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         }
     }
     auto bload = [&](uint4 (&b)[NTW * U], const uint4* __restrict__ Wp, int KT, int ct0 /*first column tile*/, int kt) {
+#if FFN_ABL2 & 1
+        for (int t = 0; t < NTW * U; ++t) b[t] = make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+        return;
+#endif
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -390,6 +399,10 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             }
     };
     auto mma = [&](f32x4_ (&acc)[MT][NTW], const uint4 (&b)[NTW * U], int ks, const unsigned char* op) {
+#if FFN_ABL2 & 2
+        for (int t = 0; t < NTW * U; ++t) asm volatile("" :: "v"(b[t].x), "v"(b[t].y), "v"(b[t].z), "v"(b[t].w));
+        return;
+#endif
         uint4 ah[MT], al[LO ? MT : 1];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     // next is in flight, across the hidden-slice epilogue and the barriers.  The kernel runs at the per-CU L2 fetch rate, which
     // is set by the bytes in flight.
     constexpr int KU = FFN_KU;
-    uint4 b0[KU][NTW * U], b1[KU][NTW * U];
+    uint4 b0[KU][NTW * U], b1[KU][NTW * U];     // (a ring of four units, three in flight, measured 40.1 vs 38.4 us: not kept)
     auto uload = [&](uint4 (&b)[KU][NTW * U], int phase /*2c: w_1, 2c+1: w_2*/, int ks0) {
         const int c = phase >> 1;
 #pragma unroll

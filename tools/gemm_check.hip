@@ -80,7 +80,7 @@ template <int MT>
 static std::vector<float> run_as(const char* name, Prob& p, int reps) {
     AsBatch ab; memset(&ab, 0, sizeof(ab));
     ab.g[0] = desc(p).g[0]; ab.wp[0] = p.Wp; ab.ng = 1;
-    const size_t lds = (size_t)16 * MT * 512 * 2 + 4 * 16 * AS_SLD * 4;
+    const size_t lds = (size_t)16 * MT * 512 * 2;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_as<RNNT_NUM_BF16X3, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((p.M + 16 * MT - 1) / (16 * MT));
     std::vector<float> first((size_t)p.M * p.N), out(first.size());
@@ -203,7 +203,7 @@ static void problem_ffn(int M, bool lno) {
 #define FFN_NW 4
 #endif
     constexpr int NW = FFN_NW;
-    const size_t lds = tail ? FFN_LDS(RNNT_NUM_BF16X3, NW) : (size_t)2 * 2 * 16 * MT * 512 + NW * 16 * AS_SLD * 4;
+    const size_t lds = FFN_LDS(RNNT_NUM_BF16X3, NW);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_as<RNNT_NUM_BF16X3, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((M + 16 * MT - 1) / (16 * MT));
     std::vector<float> first(hX.size()), out(hX.size());

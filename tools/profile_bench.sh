@@ -21,3 +21,17 @@ for leg in ${2:-step joint}; do
   echo lds $leg done
 done
 find $O -name "*.csv" | head -40
+# Summaries (the raw outputs exceed what gpurun copies back): gpurun_out/prof_<tag>_sum/, then the raw directories are removed.
+S=$R/gpurun_out/prof_${1:-x}_sum
+mkdir -p $S
+for leg in ${2:-step joint}; do
+  DB=$(find $O/kt_$leg -name "*.db" | head -1)
+  [ -n "$DB" ] && python3 $R/tools/rocpd_stats.py $DB > $S/${leg}_kernel_stats.csv
+  cp $O/bench_kt_$leg.json $S/${leg}_bench_under_kernel_trace.json
+  python3 $R/tools/mfma_summary.py $(find $O/mfma_$leg -name "*counter_collection.csv" | head -1) $S/${leg}_mfma_busy.json > /dev/null
+  python3 $R/tools/pmc_summary.py $(find $O/fetch_$leg -name "*counter_collection.csv" | head -1) $(find $O/write_$leg -name "*counter_collection.csv" | head -1) $S/${leg}_pmc_traffic.json > /dev/null
+  python3 $R/tools/lds_summary.py $(find $O/lds_$leg -name "*counter_collection.csv" | head -1) $S/${leg}_lds_valu.json
+  tail -3 $O/kt_$leg.err > $S/${leg}_kt_err_tail.txt
+done
+rm -rf $O
+ls -la $S
