@@ -576,7 +576,7 @@ def main():
         flops = Bf * 2.0 * (tq * (11.2e6 + 1.25e6 + 0.18e6 + 18.183168e6 + 9216.0 * tq))
         legs["full_context"] = {"workload": f"configs[4]: full-context encoder, batch={Bf} x 30 s (decoding_chunk_size=-1), {tq} frames per utterance", "ms_per_step": round(df * 1e3, 2),
                                 "value": round(Bf * Tn / df, 1), "unit": "audio-frames/s", "dtype": choice,
-                                "roofline": {"bound": "mfma", "kernel": "whole encoder pass = the layer-major schedule with one chunk of T frames (gemm_bw conv2, ffn_as, gemm_as, rel_attention_lm_mfma over 749 keys, dwconv_lm)", "achieved": round(flops / df / 1e12, 2),
+                                "roofline": {"bound": "mfma", "kernel": "whole encoder pass = the layer-major schedule with one chunk of T frames (gemm_bw conv2, ffn_as, gemm_as, " + ("rel_attention_lm_mfma" if choice == "fp32" else "rel_attention_lm_bf") + " over 749 keys, dwconv_lm)", "achieved": round(flops / df / 1e12, 2),
                                              "peak": PEAK_TFLOPS[choice], "unit": "TFLOP/s", "frac": round(flops / df / 1e12 / PEAK_TFLOPS[choice], 4), "traffic": None}}
         del eng, xf, of
 
