@@ -498,13 +498,13 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
                 const uint4 kh = *reinterpret_cast<const uint4*>(Kh + off);
                 if constexpr (LO) {
                     const uint4 kl = *reinterpret_cast<const uint4*>(Kl + off);
-                    acc = mfma16_<F16>(qul[s], kh, acc);
-                    acc = mfma16_<F16>(quh[s], kl, acc);
+                    acc = mfma16_<F16>(kh, qul[s], acc);
+                    acc = mfma16_<F16>(kl, quh[s], acc);
                 }
-                acc = mfma16_<F16>(quh[s], kh, acc);
+                acc = mfma16_<F16>(kh, quh[s], acc);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Sx[(16 * qt + 4 * kq + r) * LM2_LD + 16 * kt + i] = acc[r];
+            // operands swapped (bitwise the same sums): the lane holds query row 16 qt + i and keys 16 kt + 4 kq + 0..3 -> one 16-byte write
+            *reinterpret_cast<f32x4_*>(&Sx[(16 * qt + i) * LM2_LD + 16 * kt + 4 * kq]) = acc;
         }
         for (int gt = (hf ? 3 : 0); gt < (hf ? 5 : 3); ++gt) {
             f32x4_ acc = (f32x4_){0.f, 0.f, 0.f, 0.f};
@@ -514,13 +514,12 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
                 const uint4 ph = *reinterpret_cast<const uint4*>(Ph + off);
                 if constexpr (LO) {
                     const uint4 pl = *reinterpret_cast<const uint4*>(Pl + off);
-                    acc = mfma16_<F16>(qvl[s], ph, acc);
-                    acc = mfma16_<F16>(qvh[s], pl, acc);
+                    acc = mfma16_<F16>(ph, qvl[s], acc);
+                    acc = mfma16_<F16>(pl, qvh[s], acc);
                 }
-                acc = mfma16_<F16>(qvh[s], ph, acc);
+                acc = mfma16_<F16>(ph, qvh[s], acc);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Gx[(16 * qt + 4 * kq + r) * LM2_GLD + 16 * gt + i] = acc[r];
+            *reinterpret_cast<f32x4_*>(&Gx[(16 * qt + i) * LM2_GLD + 16 * gt + 4 * kq]) = acc;
         }
         __syncthreads();
         // ---- B: softmax of query slots 8*wave .. +7, lane = key (f32, as in rel_attention_lm_mfma) -----------------------------------
@@ -563,11 +562,10 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
         }
         __syncthreads();
         // ---- C: O = alpha O + P V for d tiles 2*hf, 2*hf + 1; the probabilities of row 16 qt + i, keys 32 s + 8 kq .. + 8, split here ----
+        {
+            const float a_ = al[16 * qt + i];                      // (transposed accumulators: one query row per lane)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a_ = al[16 * qt + 4 * kq + r];
-            o[0][r] *= a_;
-            o[1][r] *= a_;
+            for (int r = 0; r < 4; ++r) { o[0][r] *= a_; o[1][r] *= a_; }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -580,10 +578,10 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
                 const uint4 vh = *reinterpret_cast<const uint4*>(Vh + off);
                 if constexpr (LO) {
                     const uint4 vl = *reinterpret_cast<const uint4*>(Vl + off);
-                    o[dd] = mfma16_<F16>(pl, vh, o[dd]);
-                    o[dd] = mfma16_<F16>(ph, vl, o[dd]);
+                    o[dd] = mfma16_<F16>(vh, pl, o[dd]);
+                    o[dd] = mfma16_<F16>(vl, ph, o[dd]);
                 }
-                o[dd] = mfma16_<F16>(ph, vh, o[dd]);
+                o[dd] = mfma16_<F16>(vh, ph, o[dd]);
             }
         }
     }
@@ -592,15 +590,11 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
     for (int j = 0; j < 8; ++j)
         if (lane == 0) al[8 * wave + j] = lrun[j] > 0.f ? 1.0f / lrun[j] : 0.f;
     __syncthreads();
+    if (my_f >= 0) {                                                // query row 16 qt + i: d = 16 (2 hf + dd) + 4 kq + 0..3 -> 16-byte stores
+        const long long m = (long long)b * P.F + my_f;
+        const float li = al[16 * qt + i];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * qt + 4 * kq + r;                       // query row of accumulator register r
-        const int fr = ldgi(&blk->r[row].f);
-        if (fr >= 0) {
-            const long long m = (long long)b * P.F + fr;
-            const float li = al[row];
-#pragma unroll
-            for (int dd = 0; dd < 2; ++dd) stg1(P.out + m * RNNT_D + h * RNNT_DK + 16 * (2 * hf + dd) + i, o[dd][r] * li);
-        }
+        for (int dd = 0; dd < 2; ++dd)
+            stg4(P.out + m * RNNT_D + h * RNNT_DK + 16 * (2 * hf + dd) + 4 * kq, make_float4(o[dd][0] * li, o[dd][1] * li, o[dd][2] * li, o[dd][3] * li));
     }
 }
