@@ -20,6 +20,12 @@ __device__ long long as_trace[4096 * 8];
 #define AS_STAMP(k_)
 #endif
 #define AS_MT_ 3
+#ifndef BW_WD
+#define BW_WD 3       // k-steps the weight fragments of gemm_bw run ahead (1..3)
+#endif
+#ifndef BW_ABL
+#define BW_ABL 0     // tools/gemm_check timing experiments only (wrong results): 1 no A loads, 2 no weight loads, 4 no MFMAs, 8 no LDS stores, 16 no barriers
+#endif
 #ifndef FFN_ABL2
 #define FFN_ABL2 0   // tools/gemm_check timing experiments only: 1 no weight loads, 2 no MFMAs / A-fragment reads
 #endif
@@ -654,14 +660,15 @@ template <int NUM, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restrict__ wp) {
     using C = FuseCfg<NUM>;
     constexpr bool F16 = C::F16, LO = C::PLANES == 2;
-    constexpr int U = C::PLANES, MT = 8, NTW = 16 / NW, NT = 64 * NW, AJ = 512 / NT;   // AJ: 8-float A chunks per thread and k-step
+    constexpr int U = C::PLANES, MT = 8, NTW = 16 / NW, NT = 64 * NW, AJ = NT >= 512 ? 1 : 512 / NT;   // AJ: 8-float A chunks per thread and k-step (NW = 16: the first 512 threads stage)
     __shared__ uint4 Ah[2][512];
     __shared__ uint4 Al[LO ? 2 : 1][LO ? 512 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int bm0 = blockIdx.x * 128;
     if (bm0 >= p.M) return;
-    const int srow = tid >> 2, sc = tid & 3;
+    const int srow = (tid & 511) >> 2, sc = tid & 3;
+    const bool stager = NT <= 512 || tid < 512;
     const float* ag[AJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) ag[j] = p.A + a_row_off(p, min(bm0 + srow + (NT / 4) * j, p.M - 1));
@@ -670,12 +677,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
     // the A stream comes from HBM (1.09 GB for conv2): its loads run FOUR k-steps ahead of the MFMAs in a register ring
     float4 ra[4][AJ][2];
     auto gload = [&](float4 (&r)[AJ][2], int blk) {
+        if (BW_ABL & 1) { for (int j = 0; j < AJ; ++j) { r[j][0] = make_float4(0.5f, 0.25f, 1.f, 2.f); r[j][1] = r[j][0]; } return; }
+        if (!stager) return;
         const int kk = blk * 32 + 8 * sc;
         const long long ko = aplain ? (long long)kk : a_k_off(p, kk);
 #pragma unroll
         for (int j = 0; j < AJ; ++j) { r[j][0] = ldg4_nt(ag[j] + ko); r[j][1] = ldg4_nt(ag[j] + ko + 4); }   // streamed once: keep the weights in L2
     };
     auto lstore = [&](int buf, const float4 (&r)[AJ][2]) {
+        if (!stager) return;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int rr = srow + (NT / 4) * j;
@@ -687,6 +697,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
         }
     };
     auto bload = [&](uint4 (&b)[NTW * U], int kt) {
+        if (BW_ABL & 2) { for (int t = 0; t < NTW * U; ++t) b[t] = make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); return; }
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -707,6 +718,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
         for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
     const int fsw = q ^ bf_swz(i);
     auto mma = [&](int buf, const uint4 (&b)[NTW * U]) {
+        if (BW_ABL & 4) { for (int t = 0; t < NTW * U; ++t) asm volatile("" :: "v"(b[t].x), "v"(b[t].y), "v"(b[t].z), "v"(b[t].w)); return; }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int slot = (16 * mt + i) * 4 + fsw;
@@ -723,24 +735,40 @@ __global__ __launch_bounds__(64 * NW) void gemm_bw(GemmP p, const uint4* __restr
             }
         }
     };
-    uint4 b0[NTW * U], b1[NTW * U];
+    // weight fragments BW_WD k-steps ahead in a ring of four register sets (one k-step of MFMAs is shorter than an L2 round trip
+    // under load: with one k-step of run-ahead every k-step began with a wait)
+    uint4 wb[4][NTW * U];
 #pragma unroll
     for (int k = 0; k < 4; ++k) gload(ra[k], k);                     // KT >= 4 and KT % 4 == 0 (host check)
-    bload(b0, 0);
+#pragma unroll
+    for (int k = 0; k < BW_WD; ++k) bload(wb[k], k);
     lstore(0, ra[0]);
     __syncthreads();
+#ifdef AS_TRACE
+    long long bw_t[4] = {0, 0, 0, 0}, bw_last = __builtin_amdgcn_s_memtime();
+#define BW_STAMP(k_) { const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); bw_t[k_] += t_ - bw_last; bw_last = t_; }
+#else
+#define BW_STAMP(k_)
+#endif
     for (int blk = 0; blk < KT; blk += 4) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = blk + s;
             // LDS buffer k & 1 holds A(k); ring slots (s+1..s+3) % 4 hold A(k+1..k+3); slot s is free again
-            // loads return in issue order: the weight fragments (needed next k-step) go first, the far-ahead A rows behind them
-            if (k + 1 < KT) { if (s & 1) bload(b0, k + 1); else bload(b1, k + 1); }
+            // loads return in issue order: the weight fragments go first, the far-ahead A rows behind them
+            if (k + BW_WD < KT) bload(wb[(s + BW_WD) & 3], k + BW_WD);
             if (k + 4 < KT) gload(ra[s], k + 4);
-            if (s & 1) mma(1, b1); else mma(0, b0);
-            if (k + 1 < KT) lstore((s + 1) & 1, ra[(s + 1) & 3]);
-            __syncthreads();
+            BW_STAMP(0)                                              // load issue
+            mma(s & 1, wb[s]);
+            BW_STAMP(1)                                              // wait for the weight fragments + A fragment reads + MFMAs
+            if (k + 1 < KT && !(BW_ABL & 8)) lstore((s + 1) & 1, ra[(s + 1) & 3]);
+            BW_STAMP(2)                                              // wait for the A rows + split + LDS stores
+            if (!(BW_ABL & 16)) __syncthreads();
+            BW_STAMP(3)                                              // barrier
         }
     }
+#ifdef AS_TRACE
+    if (lane == 0 && blockIdx.x < 1024 && wave < 4) for (int k_ = 0; k_ < 4; ++k_) as_trace[(blockIdx.x * 4 + wave) * 8 + k_] = bw_t[k_];
+#endif
     as_epilogue_t<MT, NTW>(p, acc, bm0, wave * 16 * NTW, lane);
 }

@@ -291,10 +291,18 @@ int main() {
             CK(hipEventRecord(e1, 0));
             CK(hipDeviceSynchronize());
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            {
+                std::vector<long long> tr(4096 * 8);
+                CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(as_trace), tr.size() * 8));
+                double sm[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 1024; ++b) for (int k = 0; k < 4; ++k) sm[k] += (double)tr[(b * 4) * 8 + k];
+                printf("             wave 0 of the first 1024 tiles, clocks per tile: load issue %.0f, weights wait + A reads + MFMAs %.0f, A wait + split + LDS stores %.0f, barrier %.0f\n", sm[0] / 1024, sm[1] / 1024, sm[2] / 1024, sm[3] / 1024);
+            }
             printf("  %-11s %8.1f us  %7.1f TFLOP/s   == <2,2>: %d\n", nm, ms * 1e3 / 5, 2.0 * p.M * p.N * p.K / (ms * 1e3 / 5) / 1e6, (int)!memcmp(o.data(), r22.data(), o.size() * 4));
         };
         run_bw(gemm_bw<RNNT_NUM_BF16X3, 4>, 256, "gemm_bw<4>");
         run_bw(gemm_bw<RNNT_NUM_BF16X3, 8>, 512, "gemm_bw<8>");
+        run_bw(gemm_bw<RNNT_NUM_BF16X3, 16>, 1024, "gemm_bw<16>");
         return 0;
     }
     problem("ffn1 (LN + SiLU)", 12032, 1024, 256, true, EPI_SILU);
