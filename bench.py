@@ -59,7 +59,7 @@ def site_kernel(site, mode):
         if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "ffn_qkv", "out_pw1", "qkv", "pw1"):
             return {"out_pw1": "ffn_as chain (linear_out + residual, then LayerNorm + pointwise_conv1 + GLU from the result rows in LDS)",
                     "ffn_qkv": "ffn_as + tail (macaron FFN module, then LayerNorm + linear_q/k/v from its result rows in LDS; K/V rows into the cache)",
-                    "ffn": "ffn_as (LayerNorm + w_1 + SiLU + w_2 + half-step residual [+ norm_final], hidden activation in LDS, M = B*F)",
+                    "ffn": "ffn_as ([pointwise_conv2 + residual head, x' in LDS,] LayerNorm + w_1 + SiLU + w_2 + half-step residual + norm_final, hidden activation in LDS, M = B*F)",
                     "qkv": "gemm_as x3 (LayerNorm once, linear_q/k/v from one staged operand image, K/V rows into the cache)",
                     "pw1": "gemm_as (LayerNorm + pointwise_conv1 + GLU)"}[site]
         return {"conv1": "conv1_relu_rows", "conv2": ("gemm_bw (conv2 implicit GEMM of all equal-length chunks: 128x256 tiles, weights streamed from L2 in fragment order)" if bf else f"{gk} (conv2 implicit GEMM)"), "embed": f"{gk} (embed Linear)",
@@ -84,6 +84,7 @@ def site_flops_bytes(site, B, plan):
         F = sum(sub_len(b - a) for a, b in plan)
         M = B * F
         tail = os.environ.get("RNNT_LM_QKV_TAIL", "1") != "0"
+        pw2_head = os.environ.get("RNNT_LM_PW2_HEAD", "1") != "0" and os.environ.get("RNNT_AS", "1") != "0"
         kv_rows = F                                     # every frame's K/V row is written once and staged by the attention tiles
         att_fl = 0.0
         for i, (a, b) in enumerate(plan):
@@ -93,7 +94,8 @@ def site_flops_bytes(site, B, plan):
             t2 = kv if i > 0 else 0
         per = {"ffn1": (2.0 * M * 256 * 1024, 4.0 * (M * 256 + 256 * 1024 + M * 1024), 24),
                "ffn2": (2.0 * M * 256 * 1024, 4.0 * (M * 1024 + 256 * 1024 + 2 * M * 256), 24),
-               "ffn": (4.0 * M * 256 * 1024, 4.0 * (2 * M * 256 + 2 * 256 * 1024), 12 if tail else 24),      # fused module: x in, x out, both weight matrices
+               # fused module: x in, x out, both weight matrices; with the pointwise_conv2 head in front (RNNT_LM_PW2_HEAD, default) also its product, dw rows and weights
+               "ffn": ((4.0 * M * 256 * 1024 + (2.0 * M * 256 * 256 if pw2_head else 0.0), 4.0 * (2 * M * 256 + 2 * 256 * 1024 + ((M * 256 + 256 * 256) if pw2_head else 0)), 12 if tail else 24)),
                "ffn_qkv": (4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768, 4.0 * (2 * M * 256 + 2 * 256 * 1024 + 3 * 256 * 256 + 3 * M * 256), 12),   # macaron FFN + q/k/v from its result rows
                "qkv": (2.0 * M * 256 * 768, 4.0 * (M * 256 + 3 * 256 * 256 + 3 * M * 256), 12),
                "attn": (att_fl, 4.0 * (2 * B * kv_rows * 256 + 2 * M * 256 + (kv_rows + len(plan)) * 256), 12),

@@ -285,6 +285,14 @@ struct FfnP {
     // single-contraction head instead of the FFN (attention output projection): Y = X + alpha * (A0 W^T + b2) with W = w2p packed
     // [256][256]; A0 rows are staged as they are (no LayerNorm), w1p / b1 / ln_* unused
     const float* A0;
+    // optional head IN FRONT of the FFN (pointwise_conv2 + residual -> FFN, one launch): x' = X + (H0 rows * Wh^T + bh) with Wh = whp
+    // packed [256][256]; x' lives in LDS only (LN input and residual of the FFN).  hrowlen: rows m with m % hrowlen_n >= hrowlen[m /
+    // hrowlen_n] keep X (the conv module's padding mask, convolution.py:148-150).  Needs FFN_LDS + FFN_XROWS bytes of LDS.
+    const float* H0;
+    const uint4* whp;
+    const float* bh;
+    const int* hrowlen;
+    int hrowlen_n;
     GemmP tg[3];
     const uint4* twp[3];
 };
@@ -296,6 +304,7 @@ struct FfnP {
 
 // [Xop | Hop] (2 images), overlaid by the result rows [R][FFN_FLD] and, behind those, the tail's operand image
 #define FFN_LDS(NUM_, NW_) ((size_t)FFN_TIMG + (size_t)FuseCfg<NUM_>::PLANES * 16 * AS_MT_ * FuseCfg<NUM_>::ROWB)
+#define FFN_XROWS (16 * AS_MT_ * FFN_FLD * 4)      // the head's x' rows, behind everything else
 // NW waves per workgroup (4 or 8): every wave owns 256 / NW of the 256 output columns of a contraction (NTW = 16 / NW column
 // tiles).  NW = 8 puts two waves on every SIMD, so one wave's waits on weight fragments hide under the other's MFMAs.
 template <int NUM, int MT, int NW = 4>
@@ -313,79 +322,6 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     if (bm0 >= P.M) return;
     float* fin = reinterpret_cast<float*>(ffn_smem);                            // [R][FFN_FLD] after the last contraction
     static_assert(R * FFN_FLD * 4 <= FFN_TIMG && 2 * IMG <= FFN_TIMG + IMG, "result rows / both images must fit FFN_LDS");
-    // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
-    if (P.A0) {
-        constexpr int CJ = (R * 32 + NT - 1) / NT;                 // 8-float chunks per thread
-        float4 va[CJ], vb[CJ];
-#pragma unroll
-        for (int j = 0; j < CJ; ++j) {
-            const int e = min(tid + NT * j, R * 32 - 1), r = e >> 5, c = e & 31;
-            const float* ap = P.A0 + (long long)min(bm0 + r, P.M - 1) * RNNT_D + 8 * c;
-            va[j] = ldg4(ap);
-            vb[j] = ldg4(ap + 4);
-        }
-#pragma unroll
-        for (int j = 0; j < CJ; ++j) {
-            const int e = tid + NT * j, r = e >> 5, c = e & 31;
-            if (e >= R * 32) continue;
-            uint4 h, l;
-            split8_16<F16, LO>(va[j], vb[j], h, l);
-            const int off = op_off<NUM>(r, c);
-            *reinterpret_cast<uint4*>(Xop + off) = h;
-            if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
-        }
-    } else {
-        constexpr int RP = 4 * NW, NP = (R + RP - 1) / RP;         // rows per pass (4 per wave), passes
-        const int g = lane >> 4, l16 = lane & 15;
-        float4 v[NP][4];
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            const float* rp = P.X + (long long)min(bm0 + min(wave * 4 + g + RP * ps, R - 1), P.M - 1) * RNNT_D;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { v[ps][2 * j] = ldg4(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = ldg4(rp + 8 * (l16 + 16 * j) + 4); }
-        }
-        float mu[NP], rs[NP];
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            float sm = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sm += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
-            mu[ps] = sm * (1.0f / 256.0f);
-        }
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-            float qq = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dx = v[ps][j].x - mu[ps], dy = v[ps][j].y - mu[ps], dz = v[ps][j].z - mu[ps], dw = v[ps][j].w - mu[ps];
-                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
-            rs[ps] = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = l16 + 16 * j;
-            const float4 g0 = ldg4(P.ln_g + 8 * c), g1 = ldg4(P.ln_g + 8 * c + 4), b0_ = ldg4(P.ln_b + 8 * c), b1_ = ldg4(P.ln_b + 8 * c + 4);
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
-                const int r = wave * 4 + g + RP * ps;
-                if (r >= R) continue;
-                const float m_ = mu[ps], s_ = rs[ps];
-                float4 x0 = v[ps][2 * j], x1 = v[ps][2 * j + 1];
-                x0.x = (x0.x - m_) * s_ * g0.x + b0_.x; x0.y = (x0.y - m_) * s_ * g0.y + b0_.y; x0.z = (x0.z - m_) * s_ * g0.z + b0_.z; x0.w = (x0.w - m_) * s_ * g0.w + b0_.w;
-                x1.x = (x1.x - m_) * s_ * g1.x + b1_.x; x1.y = (x1.y - m_) * s_ * g1.y + b1_.y; x1.z = (x1.z - m_) * s_ * g1.z + b1_.z; x1.w = (x1.w - m_) * s_ * g1.w + b1_.w;
-                uint4 h, l;
-                split8_16<F16, LO>(x0, x1, h, l);
-                const int off = op_off<NUM>(r, c);
-                *reinterpret_cast<uint4*>(Xop + off) = h;
-                if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
-            }
-        }
-    }
     auto bload = [&](uint4 (&b)[NTW * U], const uint4* __restrict__ Wp, int KT, int ct0 /*first column tile*/, int kt) {
 #if FFN_ABL2 & 1
         for (int t = 0; t < NTW * U; ++t) b[t] = make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
@@ -433,6 +369,134 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    float* xrows = reinterpret_cast<float*>(ffn_smem + FFN_TIMG + IMG);        // [R][FFN_FLD] x' of the head (only then allocated)
+    if (P.H0) {
+        // ---- head: H0 rows -> Xop (as they are), one K = 256 contraction, x' = X + result -> xrows ------------------------------
+        constexpr int CJ = (R * 32 + NT - 1) / NT;
+        float4 va[CJ], vb[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int e = min(tid + NT * j, R * 32 - 1), r = e >> 5, c = e & 31;
+            const float* ap = P.H0 + (long long)min(bm0 + r, P.M - 1) * RNNT_D + 8 * c;
+            va[j] = ldg4(ap);
+            vb[j] = ldg4(ap + 4);
+        }
+        uint4 hb0[NTW * U], hb1[NTW * U];
+        bload(hb0, P.whp, 8, wave * NTW, 0);
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int e = tid + NT * j, r = e >> 5, c = e & 31;
+            if (e >= R * 32) continue;
+            uint4 h, l;
+            split8_16<F16, LO>(va[j], vb[j], h, l);
+            const int off = op_off<NUM>(r, c);
+            *reinterpret_cast<uint4*>(Xop + off) = h;
+            if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
+        }
+        __syncthreads();                                            // Xop complete
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+            bload(hb1, P.whp, 8, wave * NTW, ks + 1);
+            mma(yacc, hb0, ks, Xop);
+            if (ks + 2 < 8) bload(hb0, P.whp, 8, wave * NTW, ks + 2);
+            mma(yacc, hb1, ks + 1, Xop);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int col = wave * CW + 16 * t + 4 * q;
+            const float4 bb = ldg4(P.bh + col);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = 16 * mt + i, m = min(bm0 + row, P.M - 1);
+                float4 x = ldg4(P.X + (long long)m * RNNT_D + col);
+                const bool keep = P.hrowlen && (m % P.hrowlen_n) >= ldgi(P.hrowlen + m / P.hrowlen_n);
+                if (!keep) { x.x += yacc[mt][t][0] + bb.x; x.y += yacc[mt][t][1] + bb.y; x.z += yacc[mt][t][2] + bb.z; x.w += yacc[mt][t][3] + bb.w; }
+                *reinterpret_cast<float4*>(&xrows[row * FFN_FLD + col]) = x;
+                yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();                                            // x' complete, every wave is done with Xop
+    }
+    // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
+    if (P.A0) {
+        constexpr int CJ = (R * 32 + NT - 1) / NT;                 // 8-float chunks per thread
+        float4 va[CJ], vb[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int e = min(tid + NT * j, R * 32 - 1), r = e >> 5, c = e & 31;
+            const float* ap = P.A0 + (long long)min(bm0 + r, P.M - 1) * RNNT_D + 8 * c;
+            va[j] = ldg4(ap);
+            vb[j] = ldg4(ap + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int e = tid + NT * j, r = e >> 5, c = e & 31;
+            if (e >= R * 32) continue;
+            uint4 h, l;
+            split8_16<F16, LO>(va[j], vb[j], h, l);
+            const int off = op_off<NUM>(r, c);
+            *reinterpret_cast<uint4*>(Xop + off) = h;
+            if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
+        }
+    } else {
+        constexpr int RP = 4 * NW, NP = (R + RP - 1) / RP;         // rows per pass (4 per wave), passes
+        const int g = lane >> 4, l16 = lane & 15;
+        float4 v[NP][4];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int lr = min(wave * 4 + g + RP * ps, R - 1);
+            if (P.H0) {                                             // the head's x' rows (LDS)
+                const float* rp = xrows + lr * FFN_FLD;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { v[ps][2 * j] = *reinterpret_cast<const float4*>(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = *reinterpret_cast<const float4*>(rp + 8 * (l16 + 16 * j) + 4); }
+            } else {
+                const float* rp = P.X + (long long)min(bm0 + lr, P.M - 1) * RNNT_D;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { v[ps][2 * j] = ldg4(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = ldg4(rp + 8 * (l16 + 16 * j) + 4); }
+            }
+        }
+        float mu[NP], rs[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm += (v[ps][j].x + v[ps][j].y) + (v[ps][j].z + v[ps][j].w);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 16);
+            mu[ps] = sm * (1.0f / 256.0f);
+        }
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dx = v[ps][j].x - mu[ps], dy = v[ps][j].y - mu[ps], dz = v[ps][j].z - mu[ps], dw = v[ps][j].w - mu[ps];
+                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 16);
+            rs[ps] = 1.0f / sqrtf(qq * (1.0f / 256.0f) + 1e-5f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = l16 + 16 * j;
+            const float4 g0 = ldg4(P.ln_g + 8 * c), g1 = ldg4(P.ln_g + 8 * c + 4), b0_ = ldg4(P.ln_b + 8 * c), b1_ = ldg4(P.ln_b + 8 * c + 4);
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                const int r = wave * 4 + g + RP * ps;
+                if (r >= R) continue;
+                const float m_ = mu[ps], s_ = rs[ps];
+                float4 x0 = v[ps][2 * j], x1 = v[ps][2 * j + 1];
+                x0.x = (x0.x - m_) * s_ * g0.x + b0_.x; x0.y = (x0.y - m_) * s_ * g0.y + b0_.y; x0.z = (x0.z - m_) * s_ * g0.z + b0_.z; x0.w = (x0.w - m_) * s_ * g0.w + b0_.w;
+                x1.x = (x1.x - m_) * s_ * g1.x + b1_.x; x1.y = (x1.y - m_) * s_ * g1.y + b1_.y; x1.z = (x1.z - m_) * s_ * g1.z + b1_.z; x1.w = (x1.w - m_) * s_ * g1.w + b1_.w;
+                uint4 h, l;
+                split8_16<F16, LO>(x0, x1, h, l);
+                const int off = op_off<NUM>(r, c);
+                *reinterpret_cast<uint4*>(Xop + off) = h;
+                if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
+            }
+        }
+    }
     // Weight stream: per 256 hidden columns c, 8 k-steps of w_1's column group 4c + wave, then 8 k-steps of w_2's K slice c for
     // this wave's 64 output columns.  A pipeline unit = FFN_KU k-steps (8 KiB per wave each); one unit is consumed while the
     // next is in flight, across the hidden-slice epilogue and the barriers.  The kernel runs at the per-CU L2 fetch rate, which
@@ -540,7 +604,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             for (int j = 0; j < 4; ++j) {
                 const int col = 4 * (l16 + 16 * j);
                 const float4 y = *reinterpret_cast<const float4*>(&fin[row * FFN_FLD + col]);
-                const float4 x = ldg4(P.X + go + col);
+                const float4 x = P.H0 ? *reinterpret_cast<const float4*>(&xrows[row * FFN_FLD + col]) : ldg4(P.X + go + col);
                 v[j] = make_float4(x.x + P.alpha * (y.x + b2v[j].x), x.y + P.alpha * (y.y + b2v[j].y), x.z + P.alpha * (y.z + b2v[j].z), x.w + P.alpha * (y.w + b2v[j].w));
             }
             if (P.lno_g) {
