@@ -289,6 +289,10 @@ struct FfnP {
     // packed [256][256]; x' lives in LDS only (LN input and residual of the FFN).  hrowlen: rows m with m % hrowlen_n >= hrowlen[m /
     // hrowlen_n] keep X (the conv module's padding mask, convolution.py:148-150).  Needs FFN_LDS + FFN_XROWS bytes of LDS.
     const float* H0;
+    // dw.g != null: the head's input rows are not read from H0 but FORMED here: depthwise conv (k = 31, causal) + BatchNorm + SiLU of
+    // the post-GLU rows dw.g (dwconv_lm's arithmetic and ring write-back, one thread per channel and 8-row run), straight into the
+    // operand image -- the depthwise launch and its [M][256] round trip disappear (convolution.py:126-146)
+    DwLmP dw;
     const uint4* whp;
     const float* bh;
     const int* hrowlen;
@@ -370,8 +374,76 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
     float* xrows = reinterpret_cast<float*>(ffn_smem + FFN_TIMG + IMG);        // [R][FFN_FLD] x' of the head (only then allocated)
-    if (P.H0) {
-        // ---- head: H0 rows -> Xop (as they are), one K = 256 contraction, x' = X + result -> xrows ------------------------------
+    if (P.H0 || P.dw.g) {
+        // ---- head: H0 rows (or the depthwise conv's output rows, formed here) -> Xop, one K = 256 contraction, x' = X + result -> xrows ------------------------------
+        uint4 hb0[NTW * U], hb1[NTW * U];
+        bload(hb0, P.whp, 8, wave * NTW, 0);
+        if (P.dw.g) {
+            // thread = (channel c, 8-row runs tid >> 8, + NT / 256, ...): a run's rows of ONE stream share a sliding window of 8 + 30 inputs
+            static_assert(NT % 256 == 0 && R % LM_FB == 0, "one thread per channel");
+            const DwLmP& D_ = P.dw;
+            const int c = tid & 255;
+            float w[RNNT_KDW];
+#pragma unroll
+            for (int k = 0; k < RNNT_KDW; ++k) w[k] = ldg1(D_.wdw_t + k * RNNT_D + c);
+            const float bd = ldg1(D_.bdw + c), bs = ldg1(D_.bn_s + c), bt = ldg1(D_.bn_t + c);
+            // one piece = up to LM_FB consecutive rows of ONE stream starting at tile row r0: window loads (`load`), then outputs (`emit`)
+            auto load = [&](float (&win)[LM_FB + RNNT_LORDER], int r0, int& b, int& f0, int& cnt, int room) {
+                const int m0 = bm0 + r0;
+                cnt = 0; b = 0; f0 = 0;
+                if (m0 >= P.M) return;
+                b = m0 / D_.F; f0 = m0 - b * D_.F;
+                cnt = min(room, D_.F - f0);
+                const float* gb = D_.g + ((long long)b * D_.gs + f0) * RNNT_D + c;
+#pragma unroll
+                for (int i2 = 0; i2 < LM_FB + RNNT_LORDER; ++i2) win[i2] = (i2 < cnt + RNNT_LORDER) ? ldg1(gb + (long long)i2 * RNNT_D) : 0.f;
+            };
+            auto emit = [&](const float (&win)[LM_FB + RNNT_LORDER], int r0, int b, int f0, int cnt) {
+#pragma unroll
+                for (int j = 0; j < LM_FB; ++j) {
+                    if (j >= cnt) break;
+                    const int f = f0 + j;
+                    float acc = bd;
+#pragma unroll
+                    for (int k = 0; k < RNNT_KDW; ++k) acc = fmaf(w[k], win[j + k], acc);
+                    float v = acc * bs + bt;
+                    v = v * sigmoidf_(v);
+                    op_store1<NUM>(Xop, R, r0 + j, c, v);
+                    if (f >= D_.F - D_.cap) {
+                        const long long rr = ((long long)b * D_.cap + (D_.pos + f) % D_.cap) * RNNT_D + c;
+                        stg1(D_.gring + rr, win[j + RNNT_LORDER]);
+                        stg1(D_.xring + rr, ldg1(D_.xres + ((long long)b * D_.F + f) * RNNT_D + c));
+                    }
+                }
+            };
+            // this thread's runs, three at a time with all their windows in flight at once (one L2 round trip per batch, not per run)
+            constexpr int NG = NT / 256, NRUN = (R / LM_FB + NG - 1) / NG, NB = NRUN < 3 ? NRUN : 3;   // thread groups, runs per thread, batch
+            static_assert(NRUN % NB == 0, "runs per thread in batches");
+#pragma unroll
+            for (int rb = 0; rb < NRUN; rb += NB) {
+                float win[NB][LM_FB + RNNT_LORDER];
+                int pb[NB], pf[NB], pc[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int run = (tid >> 8) + NG * (rb + u);
+                    pc[u] = LM_FB; pb[u] = 0; pf[u] = 0;
+                    if (run < R / LM_FB) load(win[u], run * LM_FB, pb[u], pf[u], pc[u], LM_FB);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int run = (tid >> 8) + NG * (rb + u), r0 = run * LM_FB;
+                    if (run >= R / LM_FB) continue;
+                    emit(win[u], r0, pb[u], pf[u], pc[u]);
+                    if (pc[u] < LM_FB) {                            // the run crosses into the next stream (or ends the batch): second piece / zero rows
+                        int b2, f2, c2;
+                        float win2[LM_FB + RNNT_LORDER];
+                        load(win2, r0 + pc[u], b2, f2, c2, LM_FB - pc[u]);
+                        emit(win2, r0 + pc[u], b2, f2, c2);
+                        for (int j = pc[u] + c2; j < LM_FB; ++j) op_store1<NUM>(Xop, R, r0 + j, c, 0.f);
+                    }
+                }
+            }
+        } else {
         constexpr int CJ = (R * 32 + NT - 1) / NT;
         float4 va[CJ], vb[CJ];
 #pragma unroll
@@ -381,8 +453,6 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             va[j] = ldg4(ap);
             vb[j] = ldg4(ap + 4);
         }
-        uint4 hb0[NTW * U], hb1[NTW * U];
-        bload(hb0, P.whp, 8, wave * NTW, 0);
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int e = tid + NT * j, r = e >> 5, c = e & 31;
@@ -392,6 +462,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             const int off = op_off<NUM>(r, c);
             *reinterpret_cast<uint4*>(Xop + off) = h;
             if constexpr (LO) *reinterpret_cast<uint4*>(Xop + R * ROWB + off) = l;
+        }
         }
         __syncthreads();                                            // Xop complete
 #pragma unroll
@@ -445,7 +516,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             const int lr = min(wave * 4 + g + RP * ps, R - 1);
-            if (P.H0) {                                             // the head's x' rows (LDS)
+            if (P.H0 || P.dw.g) {                                   // the head's x' rows (LDS)
                 const float* rp = xrows + lr * FFN_FLD;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { v[ps][2 * j] = *reinterpret_cast<const float4*>(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = *reinterpret_cast<const float4*>(rp + 8 * (l16 + 16 * j) + 4); }
@@ -604,7 +675,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             for (int j = 0; j < 4; ++j) {
                 const int col = 4 * (l16 + 16 * j);
                 const float4 y = *reinterpret_cast<const float4*>(&fin[row * FFN_FLD + col]);
-                const float4 x = P.H0 ? *reinterpret_cast<const float4*>(&xrows[row * FFN_FLD + col]) : ldg4(P.X + go + col);
+                const float4 x = (P.H0 || P.dw.g) ? *reinterpret_cast<const float4*>(&xrows[row * FFN_FLD + col]) : ldg4(P.X + go + col);
                 v[j] = make_float4(x.x + P.alpha * (y.x + b2v[j].x), x.y + P.alpha * (y.y + b2v[j].y), x.z + P.alpha * (y.z + b2v[j].z), x.w + P.alpha * (y.w + b2v[j].w));
             }
             if (P.lno_g) {
