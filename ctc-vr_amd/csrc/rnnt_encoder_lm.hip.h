@@ -543,9 +543,9 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float mnew = fmaxf(mrun[j], mx[j]);
-                pe_[j] = sc[j] > -INFINITY ? expf(sc[j] - mnew) : 0.f;
+                pe_[j] = sc[j] > -INFINITY ? __builtin_amdgcn_exp2f((sc[j] - mnew) * 1.4426950408889634f) : 0.f;   // v_exp_f32 (1 ulp); the exact-f32 kernel keeps expf
                 sm[j] = pe_[j];
-                mx[j] = live[j] ? expf(mrun[j] - mnew) : 1.0f;               // alpha (first live tile: exp(-inf) = 0)
+                mx[j] = live[j] ? __builtin_amdgcn_exp2f((mrun[j] - mnew) * 1.4426950408889634f) : 1.0f;   // alpha (first live tile: exp2(-inf) = 0)
                 if (live[j]) mrun[j] = mnew;
             }
 #pragma unroll
