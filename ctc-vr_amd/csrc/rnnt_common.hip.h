@@ -150,6 +150,23 @@ __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic, int shift) 
 // moved a near-tie token relative to the per-chunk path, and dropped it).  exp2(+inf) = inf -> rcp -> 0; exp2(-inf) = 0 -> 1.
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
+// The value of the butterfly partner lane ^ O for an ALL-REDUCE whose earlier steps ran in ascending O (1, 2, 4, ...): for O <= 8 a DPP
+// modifier instead of the ds_bpermute __shfl_xor compiles to (quad permutes for 1 and 2; row_half_mirror / row_mirror for 4 and 8,
+// which hand over lane 7 - i / 15 - i: the same VALUE as lane i ^ 4 / i ^ 8 once the quads / 8-groups are uniform, so the reduction
+// is bitwise the butterfly's).  16 and 32 cross DPP rows and stay shuffles.
+template <int O>
+__device__ __forceinline__ float xor_partner(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (O == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    else if constexpr (O == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    else if constexpr (O == 4) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    else if constexpr (O == 8) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    else return __shfl_xor(v, O, 64);
+#else
+    return v;
+#endif
+}
+// (descending butterfly, bitwise the reductions every schedule has shared since round 1: not re-ordered)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -536,10 +536,11 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
                 sc[j] = valid ? (Sx[qs * LM2_LD + lane] + Gx[qs * LM2_GLD + lane + s_prel[j]]) * 0.125f : -INFINITY;
                 mx[j] = sc[j];
             }
-#pragma unroll
-            for (int o_ = 32; o_ > 0; o_ >>= 1)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], o_, 64));
+            // all-reduce over the 64 keys, ascending butterfly (DPP partners for 1..8: rnnt_common.hip.h), the 8 rows interleaved
+#define LMB_RED(O_, EXPR_) _Pragma("unroll") for (int j = 0; j < 8; ++j) { const float o_ = xor_partner<O_>(RV_[j]); RV_[j] = EXPR_; }
+#define RV_ mx
+            LMB_RED(1, fmaxf(RV_[j], o_)) LMB_RED(2, fmaxf(RV_[j], o_)) LMB_RED(4, fmaxf(RV_[j], o_)) LMB_RED(8, fmaxf(RV_[j], o_)) LMB_RED(16, fmaxf(RV_[j], o_)) LMB_RED(32, fmaxf(RV_[j], o_))
+#undef RV_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float mnew = fmaxf(mrun[j], mx[j]);
@@ -548,10 +549,10 @@ __global__ __launch_bounds__(256) void rel_attention_lm_bf(LmAttnP P) {
                 mx[j] = live[j] ? __builtin_amdgcn_exp2f((mrun[j] - mnew) * 1.4426950408889634f) : 1.0f;   // alpha (first live tile: exp2(-inf) = 0)
                 if (live[j]) mrun[j] = mnew;
             }
-#pragma unroll
-            for (int o_ = 32; o_ > 0; o_ >>= 1)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sm[j] += __shfl_xor(sm[j], o_, 64);
+#define RV_ sm
+            LMB_RED(1, RV_[j] + o_) LMB_RED(2, RV_[j] + o_) LMB_RED(4, RV_[j] + o_) LMB_RED(8, RV_[j] + o_) LMB_RED(16, RV_[j] + o_) LMB_RED(32, RV_[j] + o_)
+#undef RV_
+#undef LMB_RED
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int qs = 8 * wave + j;
