@@ -1009,12 +1009,11 @@ __global__ __launch_bounds__(512) void greedy_multi(DecMP p) {
                 v = ((lpart[(k * 4) * 128 + r] + lpart[(k * 4 + 1) * 128 + r]) + (lpart[(k * 4 + 2) * 128 + r] + lpart[(k * 4 + 3) * 128 + r])) + ldg1(p.bout + vr);
                 ix = vr;
             }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const float ov = __shfl_xor(v, o, 64);
-                const int oi = __shfl_xor(ix, o, 64);
-                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-            }
+            // ascending butterfly; DPP partners for 1..8 (xor_partner: the (value, index) pair is uniform in quads / 8-groups by then)
+#define GM_STEP(O_) { const float ov = xor_partner<O_>(v); const int oi = __builtin_bit_cast(int, xor_partner<O_>(__builtin_bit_cast(float, ix))); \
+                      if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; } }
+            GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8) GM_STEP(16) GM_STEP(32)
+#undef GM_STEP
             if (lane == 0) { redv[wave] = v; redi[wave] = ix; }   // wave 2 k, 2 k + 1 = frame k
         }
         __syncthreads();
