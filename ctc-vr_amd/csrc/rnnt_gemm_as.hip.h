@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
     using C = FuseCfg<NUM>;
     constexpr bool F16 = C::F16, LO = C::PLANES == 2;
     constexpr int U = C::PLANES, R = 16 * MT, ROWB = C::ROWB, IMG = U * R * ROWB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];   // [Xop | Hop | per-wave staging]; the result rows overlay Xop/Hop
+    extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];   // [Xop | Hop]; the result rows overlay them, the tail's image sits at FFN_TIMG, the head's x' rows behind FFN_LDS
     unsigned char* Xop = ffn_smem;
     unsigned char* Hop = ffn_smem + IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
