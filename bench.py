@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 # launch-site tags of rnnt_profile_begin (include/rnnt_hip.h)
 TAGS = {"conv1": 1, "conv2": 2, "embed": 3, "ffn1": 4, "ffn2": 5, "qkv": 6, "attn": 7, "attn_out": 8, "pw1": 9,
-        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33, "out_pw1": 34}
+        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33, "out_pw1": 34, "ffn_merged": 35}
 TAG_JOINT_OUT = 23   # the lattice kernel's launch site (host_launch.hip.inc)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak of the operand type
 MFMA_PER_ALG = {"fp32": 1, "bf16x3": 3, "f16x3": 3, "bf16": 1}                      # MFMA products issued per algorithmic product
@@ -59,6 +59,7 @@ def site_kernel(site, mode):
         if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "ffn_qkv", "out_pw1", "qkv", "pw1"):
             return {"out_pw1": "ffn_as chain (linear_out + residual, then LayerNorm + pointwise_conv1 + GLU from the result rows in LDS)",
                     "ffn_qkv": "ffn_as + tail (macaron FFN module, then LayerNorm + linear_q/k/v from its result rows in LDS; K/V rows into the cache)",
+                    "ffn_merged": "ffn_as, layer boundary in one launch: depthwise conv + pointwise_conv2 head, FFN + norm_final of layer l, then layer l+1's macaron FFN on the result rows in LDS and LayerNorm + linear_q/k/v from those",
                     "ffn": "ffn_as ([pointwise_conv2 + residual head, x' in LDS,] LayerNorm + w_1 + SiLU + w_2 + half-step residual + norm_final, hidden activation in LDS, M = B*F)",
                     "qkv": "gemm_as x3 (LayerNorm once, linear_q/k/v from one staged operand image, K/V rows into the cache)",
                     "pw1": "gemm_as (LayerNorm + pointwise_conv1 + GLU)"}[site]
@@ -85,6 +86,7 @@ def site_flops_bytes(site, B, plan):
         M = B * F
         tail = os.environ.get("RNNT_LM_QKV_TAIL", "1") != "0"
         pw2_head = os.environ.get("RNNT_LM_PW2_HEAD", "1") != "0" and os.environ.get("RNNT_AS", "1") != "0"
+        merged = pw2_head and tail and os.environ.get("RNNT_LM_FFN_MERGE", "0") != "0"   # (off by default) 11 layer boundaries in one launch each: the plain sites keep one launch
         kv_rows = F                                     # every frame's K/V row is written once and staged by the attention tiles
         att_fl = 0.0
         for i, (a, b) in enumerate(plan):
@@ -95,8 +97,10 @@ def site_flops_bytes(site, B, plan):
         per = {"ffn1": (2.0 * M * 256 * 1024, 4.0 * (M * 256 + 256 * 1024 + M * 1024), 24),
                "ffn2": (2.0 * M * 256 * 1024, 4.0 * (M * 1024 + 256 * 1024 + 2 * M * 256), 24),
                # fused module: x in, x out, both weight matrices; with the pointwise_conv2 head in front (RNNT_LM_PW2_HEAD, default) also its product, dw rows and weights
-               "ffn": ((4.0 * M * 256 * 1024 + (2.0 * M * 256 * 256 if pw2_head else 0.0), 4.0 * (2 * M * 256 + 2 * 256 * 1024 + ((M * 256 + 256 * 256) if pw2_head else 0)), 12 if tail else 24)),
-               "ffn_qkv": (4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768, 4.0 * (2 * M * 256 + 2 * 256 * 1024 + 3 * 256 * 256 + 3 * M * 256), 12),   # macaron FFN + q/k/v from its result rows
+               "ffn": ((4.0 * M * 256 * 1024 + (2.0 * M * 256 * 256 if pw2_head else 0.0), 4.0 * (2 * M * 256 + 2 * 256 * 1024 + ((M * 256 + 256 * 256) if pw2_head else 0)), 1 if merged else (12 if tail else 24))),
+               # layer boundary in one launch (RNNT_LM_FFN_MERGE=1): head + FFN + norm_final of layer l, macaron FFN + q/k/v of layer l + 1
+               "ffn_merged": (8.0 * M * 256 * 1024 + 2.0 * M * 256 * 256 + 2.0 * M * 256 * 768, 4.0 * (3 * M * 256 + 4 * 256 * 1024 + 4 * 256 * 256 + 3 * M * 256), 11),
+               "ffn_qkv": (4.0 * M * 256 * 1024 + 2.0 * M * 256 * 768, 4.0 * (2 * M * 256 + 2 * 256 * 1024 + 3 * 256 * 256 + 3 * M * 256), 1 if merged else 12),   # macaron FFN + q/k/v from its result rows
                "qkv": (2.0 * M * 256 * 768, 4.0 * (M * 256 + 3 * 256 * 256 + 3 * M * 256), 12),
                "attn": (att_fl, 4.0 * (2 * B * kv_rows * 256 + 2 * M * 256 + (kv_rows + len(plan)) * 256), 12),
                "attn_out": (2.0 * M * 256 * 256, 4.0 * (M * 256 + 256 * 256 + 2 * M * 256), 12),
@@ -177,7 +181,7 @@ def pmc_traffic(kernel_prefixes):
 
 PMC_PREFIX = {"block_front": ["void block_front"], "block_back": ["void block_back"], "conv2": ["void gemm_bw", "void gemm_bf<2, false, 4, 4", "void gemm_ns<2, 2, 32"],
               "attn": ["void rel_attention_lm_bf", "rel_attention_lm_mfma", "rel_attention_stream_tab"], "ffn2": ["void gemm_ns_tab<1, 1, 64"], "dwconv": ["dwconv_lm", "dwconv_bn_silu_tab"],
-              "ffn": ["void ffn_as"], "ffn_qkv": ["void ffn_as"], "conv1": ["conv1_relu_rows"]}
+              "ffn": ["void ffn_as"], "ffn_qkv": ["void ffn_as"], "ffn_merged": ["void ffn_as"], "out_pw1": ["void ffn_as"], "conv1": ["conv1_relu_rows"]}
 
 
 def spawn_ranks(args):
@@ -310,7 +314,7 @@ def main():
         return sb.decode_script(x, args.chunk, pipelined=True)
 
     # ---- site survey (untimed): one step per launch site -> which kernel dominates -------------------------------------------
-    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn_qkv", "out_pw1", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
+    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn_qkv", "ffn_merged", "out_pw1", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
     survey = {}
     for _ in range(args.warmup):
         toks = step()
@@ -402,7 +406,7 @@ def main():
         if tr:
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
-            if site in ("ffn", "ffn_qkv", "out_pw1"):   # one kernel name for three launch kinds: the profile cannot tell them apart
+            if site in ("ffn", "ffn_qkv", "ffn_merged", "out_pw1"):   # one kernel name for three launch kinds: the profile cannot tell them apart
                 roofline["traffic_note"] = "mean over ALL ffn_as launches of the step (FFN + q/k/v, linear_out + pointwise_conv1, FFN + norm_final share one kernel name), not this site alone"
     other_sites = {k: v for k, v in live.items() if k != site}
 

@@ -278,6 +278,13 @@ struct FfnP {
     const float *lno_g, *lno_b;       // norm_final (null: off)
     float alpha;
     int M;
+    // optional SECOND FFN module applied to the first one's result rows while they are in LDS (w1p2 != null): the layer's last
+    // launch continues into the next layer's macaron FFN (both are row-local), Y = r1 + alpha2 * FFN2(LN2(r1)), r1 = the first
+    // module's result (after norm_final); the tail then belongs to the second module.  Needs FFN_LDS + FFN_XROWS bytes of LDS.
+    const float *ln_g2, *ln_b2;
+    const uint4 *w1p2, *w2p2;
+    const float *b1_2, *b2_2;
+    float alpha2;
     // optional tail (FFN-macaron -> self-attention projections): n_tail matrices applied to LN_t(result rows), K = 256, N = 256
     // each, epilogue / output map from the descriptors (linear_q to a buffer, linear_k / linear_v rows into the cache)
     int n_tail;
@@ -488,6 +495,51 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         }
         __syncthreads();                                            // x' complete, every wave is done with Xop
     }
+    // the parameters of the FFN module being run (two modules when w1p2 is set)
+    const float *ln_g = P.ln_g, *ln_b = P.ln_b, *b1p = P.b1, *b2p = P.b2, *lno_g = P.lno_g, *lno_b = P.lno_b;
+    const uint4 *w1p = P.w1p, *w2p = P.w2p;
+    float alpha = P.alpha;
+    // Weight stream: per 256 hidden columns c, 8 k-steps of w_1's column group 4c + wave, then 8 k-steps of w_2's K slice c for
+    // this wave's 64 output columns.  A pipeline unit = FFN_KU k-steps (8 KiB per wave each); one unit is consumed while the
+    // next is in flight, across the hidden-slice epilogue and the barriers.  The kernel runs at the per-CU L2 fetch rate, which
+    // is set by the bytes in flight.
+    constexpr int KU = FFN_KU;
+    uint4 b0[KU][NTW * U], b1[KU][NTW * U];     // (a ring of four units, three in flight, measured 40.1 vs 38.4 us: not kept)
+    auto uload = [&](uint4 (&b)[KU][NTW * U], int phase /*2c: w_1, 2c+1: w_2*/, int ks0) {
+        const int c = phase >> 1;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            if (phase & 1) bload(b[k], w2p, 32, wave * NTW, c * 8 + ks0 + k);
+            else bload(b[k], w1p, 8, c * 16 + wave * NTW, ks0 + k);
+        }
+    };
+    auto umma = [&](f32x4_ (&acc)[MT][NTW], const uint4 (&b)[KU][NTW * U], int ks0, const unsigned char* op) {
+#pragma unroll
+        for (int k = 0; k < KU; ++k) mma(acc, b[k], ks0 + k, op);
+    };
+    // the tail (units of this wave: see there); the first matrix's first weight
+    // unit is requested here, so it is in flight across the result-row phase (the weight stream would idle there otherwise)
+    auto tload = [&](uint4 (&b)[KU][NTW * U], const uint4* Wp, int ct0, int ks0) {
+#pragma unroll
+        for (int k = 0; k < KU; ++k) bload(b[k], Wp, 8, ct0, ks0 + k);
+    };
+    constexpr int NPS = (R + 4 * NW - 1) / (4 * NW);            // result-row passes (4 NW rows each)
+    float4 ykeep[NPS][4];
+    const int n_mod = (P.w1p2 && !P.A0) ? 2 : 1;
+    bool xl = P.H0 || P.dw.g;                                       // the module's input rows live in xrows (LDS), not in P.X
+    // (two straight-line copies, not a rolled loop: around a rolled one hipcc hoists the per-lane weight addresses of both modules
+    // and spills 160 registers)
+#pragma unroll
+    for (int mod = 0; mod < 2; ++mod) {
+    if (mod >= n_mod) break;
+    const bool last = mod + 1 == n_mod;
+    if (mod == 1) {
+        ln_g = P.ln_g2; ln_b = P.ln_b2; b1p = P.b1_2; b2p = P.b2_2; lno_g = nullptr; lno_b = nullptr; w1p = P.w1p2; w2p = P.w2p2; alpha = P.alpha2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) yacc[mt][t] = (f32x4_){0.f, 0.f, 0.f, 0.f};
+    }
     // ---- LN(x rows) -> Xop: 16 lanes per row, 4 rows per wave and pass ---------------------------------------------------------
     if (P.A0) {
         constexpr int CJ = (R * 32 + NT - 1) / NT;                 // 8-float chunks per thread
@@ -516,7 +568,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             const int lr = min(wave * 4 + g + RP * ps, R - 1);
-            if (P.H0 || P.dw.g) {                                   // the head's x' rows (LDS)
+            if (xl) {                                               // the head's x' rows / the first module's result rows (LDS)
                 const float* rp = xrows + lr * FFN_FLD;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { v[ps][2 * j] = *reinterpret_cast<const float4*>(rp + 8 * (l16 + 16 * j)); v[ps][2 * j + 1] = *reinterpret_cast<const float4*>(rp + 8 * (l16 + 16 * j) + 4); }
@@ -551,7 +603,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int c = l16 + 16 * j;
-            const float4 g0 = ldg4(P.ln_g + 8 * c), g1 = ldg4(P.ln_g + 8 * c + 4), b0_ = ldg4(P.ln_b + 8 * c), b1_ = ldg4(P.ln_b + 8 * c + 4);
+            const float4 g0 = ldg4(ln_g + 8 * c), g1 = ldg4(ln_g + 8 * c + 4), b0_ = ldg4(ln_b + 8 * c), b1_ = ldg4(ln_b + 8 * c + 4);
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
                 const int r = wave * 4 + g + RP * ps;
@@ -568,24 +620,6 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             }
         }
     }
-    // Weight stream: per 256 hidden columns c, 8 k-steps of w_1's column group 4c + wave, then 8 k-steps of w_2's K slice c for
-    // this wave's 64 output columns.  A pipeline unit = FFN_KU k-steps (8 KiB per wave each); one unit is consumed while the
-    // next is in flight, across the hidden-slice epilogue and the barriers.  The kernel runs at the per-CU L2 fetch rate, which
-    // is set by the bytes in flight.
-    constexpr int KU = FFN_KU;
-    uint4 b0[KU][NTW * U], b1[KU][NTW * U];     // (a ring of four units, three in flight, measured 40.1 vs 38.4 us: not kept)
-    auto uload = [&](uint4 (&b)[KU][NTW * U], int phase /*2c: w_1, 2c+1: w_2*/, int ks0) {
-        const int c = phase >> 1;
-#pragma unroll
-        for (int k = 0; k < KU; ++k) {
-            if (phase & 1) bload(b[k], P.w2p, 32, wave * NTW, c * 8 + ks0 + k);
-            else bload(b[k], P.w1p, 8, c * 16 + wave * NTW, ks0 + k);
-        }
-    };
-    auto umma = [&](f32x4_ (&acc)[MT][NTW], const uint4 (&b)[KU][NTW * U], int ks0, const unsigned char* op) {
-#pragma unroll
-        for (int k = 0; k < KU; ++k) mma(acc, b[k], ks0 + k, op);
-    };
     if (P.A0) {
         bload(b0[0], P.w2p, 8, wave * NTW, 0);
         __syncthreads();                                            // Xop complete
@@ -617,7 +651,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         {
             // hidden columns c*256 + wave*CW .. +CW = silu(acc + b1) -> Hop straight from the (transposed) C layout: a lane holds 4
             // consecutive columns of one row = an 8-byte half chunk of each plane (39.8 -> 38.5 us against the round-2 staging round trip)
-            const float* bp = P.b1 + c * 256 + wave * CW + 4 * q;
+            const float* bp = b1p + c * 256 + wave * CW + 4 * q;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const float4 bb = ldg4(bp + 16 * t);
@@ -641,13 +675,7 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         __syncthreads();                                            // every wave is done with Hop (after the last slice: with Xop too)
     }
     }
-    // the tail (units of this wave: see there); the first matrix's first weight
-    // unit is requested here, so it is in flight across the result-row phase (the weight stream would idle there otherwise)
-    auto tload = [&](uint4 (&b)[KU][NTW * U], const uint4* Wp, int ct0, int ks0) {
-#pragma unroll
-        for (int k = 0; k < KU; ++k) bload(b[k], Wp, 8, ct0, ks0 + k);
-    };
-    if (P.n_tail > 0) { tload(b0, P.twp[0], wave * NTW, 0); tload(b1, P.twp[0], wave * NTW, KU); }   // (both buffers: a load issued behind the Y stores waits for their acknowledgement)
+    if (last && P.n_tail > 0) { tload(b0, P.twp[0], wave * NTW, 0); tload(b1, P.twp[0], wave * NTW, KU); }   // (both buffers: a load issued behind the Y stores waits for their acknowledgement)
     // ---- result rows through LDS: residual, optional norm_final, float4 stores -------------------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -655,15 +683,13 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
         for (int t = 0; t < NTW; ++t)
             *reinterpret_cast<f32x4_*>(&fin[(16 * mt + i) * FFN_FLD + wave * CW + 16 * t + 4 * q]) = yacc[mt][t];
     __syncthreads();
-    constexpr int NPS = (R + 4 * NW - 1) / (4 * NW);            // result-row passes (4 NW rows each)
-    float4 ykeep[NPS][4];
     {
         const int l16 = tid & 15;
         float4 b2v[4], gv[4], bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            b2v[j] = ldg4(P.b2 + 4 * (l16 + 16 * j));
-            if (P.lno_g) { gv[j] = ldg4(P.lno_g + 4 * (l16 + 16 * j)); bv[j] = ldg4(P.lno_b + 4 * (l16 + 16 * j)); }
+            b2v[j] = ldg4(b2p + 4 * (l16 + 16 * j));
+            if (lno_g) { gv[j] = ldg4(lno_g + 4 * (l16 + 16 * j)); bv[j] = ldg4(lno_b + 4 * (l16 + 16 * j)); }
         }
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
@@ -675,10 +701,10 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
             for (int j = 0; j < 4; ++j) {
                 const int col = 4 * (l16 + 16 * j);
                 const float4 y = *reinterpret_cast<const float4*>(&fin[row * FFN_FLD + col]);
-                const float4 x = (P.H0 || P.dw.g) ? *reinterpret_cast<const float4*>(&xrows[row * FFN_FLD + col]) : ldg4(P.X + go + col);
-                v[j] = make_float4(x.x + P.alpha * (y.x + b2v[j].x), x.y + P.alpha * (y.y + b2v[j].y), x.z + P.alpha * (y.z + b2v[j].z), x.w + P.alpha * (y.w + b2v[j].w));
+                const float4 x = xl ? *reinterpret_cast<const float4*>(&xrows[row * FFN_FLD + col]) : ldg4(P.X + go + col);
+                v[j] = make_float4(x.x + alpha * (y.x + b2v[j].x), x.y + alpha * (y.y + b2v[j].y), x.z + alpha * (y.z + b2v[j].z), x.w + alpha * (y.w + b2v[j].w));
             }
-            if (P.lno_g) {
+            if (lno_g) {
                 float sm = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -699,6 +725,11 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
                     v[j].x = v[j].x * rstd * gv[j].x + bv[j].x; v[j].y = v[j].y * rstd * gv[j].y + bv[j].y;
                     v[j].z = v[j].z * rstd * gv[j].z + bv[j].z; v[j].w = v[j].w * rstd * gv[j].w + bv[j].w;
                 }
+            }
+            if (!last) {                                            // the second module's input rows (same thread reads and writes a cell)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&xrows[row * FFN_FLD + 4 * (l16 + 16 * j)]) = v[j];
+                continue;
             }
             if (P.n_tail > 0) {                                     // with a tail the rows are stored behind its contractions (see there)
 #pragma unroll
@@ -731,6 +762,8 @@ __global__ __launch_bounds__(64 * NW) void ffn_as(FfnP P) {
                 }
             }
         }
+    }
+    if (!last) { xl = true; __syncthreads(); }                      // result rows complete in xrows; every thread is done with fin (= the images' space)
     }
     if (P.n_tail > 0) {
         static_assert(R * FFN_FLD * 4 <= FFN_TIMG, "the tail image must start behind the result rows");
