@@ -38,7 +38,8 @@ sys.path.insert(0, ROOT)
 
 # launch-site tags of rnnt_profile_begin (include/rnnt_hip.h)
 TAGS = {"conv1": 1, "conv2": 2, "embed": 3, "ffn1": 4, "ffn2": 5, "qkv": 6, "attn": 7, "attn_out": 8, "pw1": 9,
-        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33, "out_pw1": 34, "ffn_merged": 35}
+        "dwconv": 10, "pw2": 11, "enc_proj": 13, "block_front": 30, "block_back": 31, "ffn": 32, "ffn_qkv": 33, "out_pw1": 34, "ffn_merged": 35,
+        "conv1_minor": 36, "conv2_minor": 37, "embed_minor": 38}
 TAG_JOINT_OUT = 23   # the lattice kernel's launch site (host_launch.hip.inc)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "f16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md: dense MFMA peak of the operand type
 MFMA_PER_ALG = {"fp32": 1, "bf16x3": 3, "f16x3": 3, "bf16": 1}                      # MFMA products issued per algorithmic product
@@ -56,13 +57,15 @@ def site_kernel(site, mode):
     gk = "gemm_bf" if bf else "gemm_ns"
     lm = os.environ.get("RNNT_LM", "1") != "0"          # layer-major schedule: one launch per layer over all B*F rows
     if lm:
-        if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "ffn_qkv", "out_pw1", "qkv", "pw1"):
+        if bf and os.environ.get("RNNT_AS", "1") != "0" and site in ("ffn", "ffn_qkv", "ffn_merged", "out_pw1", "qkv", "pw1"):
             return {"out_pw1": "ffn_as chain (linear_out + residual, then LayerNorm + pointwise_conv1 + GLU from the result rows in LDS)",
                     "ffn_qkv": "ffn_as + tail (macaron FFN module, then LayerNorm + linear_q/k/v from its result rows in LDS; K/V rows into the cache)",
                     "ffn_merged": "ffn_as, layer boundary in one launch: depthwise conv + pointwise_conv2 head, FFN + norm_final of layer l, then layer l+1's macaron FFN on the result rows in LDS and LayerNorm + linear_q/k/v from those",
                     "ffn": "ffn_as ([pointwise_conv2 + residual head, x' in LDS,] LayerNorm + w_1 + SiLU + w_2 + half-step residual + norm_final, hidden activation in LDS, M = B*F)",
                     "qkv": "gemm_as x3 (LayerNorm once, linear_q/k/v from one staged operand image, K/V rows into the cache)",
                     "pw1": "gemm_as (LayerNorm + pointwise_conv1 + GLU)"}[site]
+        if site.endswith("_minor"):
+            return {"conv1_minor": "conv1_relu (the call's tail chunk class)", "conv2_minor": f"{gk} (conv2 implicit GEMM of the tail chunk class)", "embed_minor": f"{gk} (embed Linear of the tail chunk class)"}[site]
         return {"conv1": "conv1_relu_rows", "conv2": ("gemm_bw (conv2 implicit GEMM of all equal-length chunks: 128x256 tiles, weights streamed from L2 in fragment order)" if bf else f"{gk} (conv2 implicit GEMM)"), "embed": f"{gk} (embed Linear)",
                 "ffn1": f"{gk} (ffn w_1 + LayerNorm prologue + SiLU, M = B*F)", "ffn2": f"{gk} (ffn w_2 + half-step residual, M = B*F)",
                 "qkv": f"{gk} x3 (linear_q/k/v + LayerNorm prologue, K/V rows into the cache)", "attn_out": f"{gk} (linear_out + residual)",
@@ -81,7 +84,7 @@ def site_flops_bytes(site, B, plan):
     FLOPs are the same sums; bytes count a layer's weights, K/V rows and conv rows once per layer instead of once per chunk."""
     fl = by = 0.0
     t2 = 0
-    if os.environ.get("RNNT_LM", "1") != "0" and site not in ("conv1", "conv2", "embed", "block_front", "block_back"):
+    if os.environ.get("RNNT_LM", "1") != "0" and site not in ("conv1", "conv2", "embed", "conv1_minor", "conv2_minor", "embed_minor", "block_front", "block_back"):
         F = sum(sub_len(b - a) for a, b in plan)
         M = B * F
         tail = os.environ.get("RNNT_LM_QKV_TAIL", "1") != "0"
@@ -111,7 +114,14 @@ def site_flops_bytes(site, B, plan):
                "enc_proj": (2.0 * M * 256 * 256, 4.0 * (2 * M * 256 + 256 * 256), 1)}
         f, y, cnt = per[site]
         return f * cnt, y * cnt
+    # layer-major call: the subsampling launches of the call's main chunk class (the length of the first chunk) and of the other
+    # classes (the tail chunk) are profiled as different sites (`*_minor`), so a site's average is over launches of one kind
+    lm_call = os.environ.get("RNNT_LM", "1") != "0"
+    minor_site = site.endswith("_minor")
+    base = site[:-6] if minor_site else site
     for i, (a, b) in enumerate(plan):
+        if lm_call and base in ("conv1", "conv2", "embed") and ((b - a) != (plan[0][1] - plan[0][0])) != minor_site:
+            continue
         tq = sub_len(b - a)
         t1 = (b - a - 3) // 2 + 1
         M = B * tq
@@ -132,8 +142,8 @@ def site_flops_bytes(site, B, plan):
                # fused half blocks: every contraction of the half, weights once per (chunk, layer) pair, x in and out (+ q/k/v or att rows)
                "block_front": (2.0 * M * w_front, 4.0 * (w_front + 2 * M * 256 + 3 * M * 256), 12),
                "block_back": (2.0 * M * w_back, 4.0 * (w_back + 3 * M * 256 + B * 30 * 256 + 2 * M * 256), 12)}
-        if site in per:
-            f, y, cnt = per[site]
+        if base in per:
+            f, y, cnt = per[base]
             fl += f * cnt
             by += y * cnt
         t2 = kv if i > 0 else 0    # first chunk's K/V are dropped (required_cache_size = 0)
@@ -314,7 +324,7 @@ def main():
         return sb.decode_script(x, args.chunk, pipelined=True)
 
     # ---- site survey (untimed): one step per launch site -> which kernel dominates -------------------------------------------
-    sites = ["conv1", "conv2", "embed", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn_qkv", "ffn_merged", "out_pw1", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
+    sites = ["conv1", "conv2", "embed", "conv1_minor", "conv2_minor", "embed_minor", "attn", "enc_proj", "block_front", "block_back", "ffn", "ffn_qkv", "ffn_merged", "out_pw1", "ffn1", "ffn2", "qkv", "attn_out", "pw1", "pw2", "dwconv"]   # sites without launches drop out
     survey = {}
     for _ in range(args.warmup):
         toks = step()

@@ -130,6 +130,9 @@ struct rnnt_ctx {
     int use_lm = 1;                            // RNNT_LM=0: wavefront schedule for every whole-utterance call
     float *lm_x = nullptr, *lm_h = nullptr, *lm_q = nullptr, *lm_a = nullptr, *lm_d = nullptr, *lm_g = nullptr, *lm_y1 = nullptr, *lm_y2 = nullptr;
     size_t lm_y1_cap = 0, lm_y2_cap = 0, lm_blocks_cap = 0;
+    float *lm_y1b = nullptr, *lm_y2b = nullptr;      // slabs of the tail chunk class (subsampled on sub_stream beside the main class)
+    size_t lm_y1b_cap = 0, lm_y2b_cap = 0;
+    hipEvent_t sub_ev[2] = {nullptr, nullptr};     // fork / join of the tail class on sub_stream
     // ragged batches (rnnt_decode_ragged): gathered tail frames, their subsampled rows, gather / scatter entries
     float *rg_fb = nullptr, *rg_xt = nullptr;
     int2* rg_ent = nullptr;
