@@ -128,6 +128,10 @@ struct rnnt_ctx {
     // layer-major schedule (host_lm.hip.inc): activations over all B*F rows of a call, per-layer linear post-GLU rows, one
     // subsampling slab, attention block table (reused while the plan and the entry state stay the same)
     int use_lm = 1;                            // RNNT_LM=0: wavefront schedule for every whole-utterance call
+    int lm_pw2_head = 2;                       // RNNT_LM_PW2_HEAD: 2 depthwise conv + pointwise_conv2 inside the FFN launch, 1 only pointwise_conv2, 0 three launches
+    int lm_ffn_merge = 0;                      // RNNT_LM_FFN_MERGE=1: one launch per layer boundary (better alone, worse with two batches in flight)
+    int lm_qkv_tail = 1, lm_out_chain = 1;     // RNNT_LM_QKV_TAIL=0 / RNNT_LM_OUT_CHAIN=0: q/k/v and pointwise_conv1 as launches of their own
+    int lm_side = 1;                           // RNNT_LM_SIDE=0: the tail chunk class's subsampling in line instead of on the side stream
     float *lm_x = nullptr, *lm_h = nullptr, *lm_q = nullptr, *lm_a = nullptr, *lm_d = nullptr, *lm_g = nullptr, *lm_y1 = nullptr, *lm_y2 = nullptr;
     size_t lm_y1_cap = 0, lm_y2_cap = 0, lm_blocks_cap = 0;
     float *lm_y1b = nullptr, *lm_y2b = nullptr;      // slabs of the tail chunk class (subsampled on sub_stream beside the main class)

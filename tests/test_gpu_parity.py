@@ -389,6 +389,30 @@ def test_alternative_decoder_paths(np_state_dict, env, monkeypatch):
             assert toks[i] == (g0, g1)[i % 2]["tokens"].tolist(), (env, mode, i)
 
 
+@pytest.mark.parametrize("env", [{}, {"RNNT_LM_PW2_HEAD": "0"}, {"RNNT_LM_PW2_HEAD": "1"}, {"RNNT_LM_FFN_MERGE": "1"}, {"RNNT_LM_SIDE": "0"},
+                                 {"RNNT_LM_QKV_TAIL": "0"}, {"RNNT_LM_OUT_CHAIN": "0"}])
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_layer_major_fusion_variants(np_state_dict, env, mode, monkeypatch):
+    """The fusions of the layer-major schedule are re-orderings of the same arithmetic: with the depthwise conv / pointwise_conv2 head
+    inside the FFN launch or as launches of their own, with one launch per layer boundary, with the tail chunk class's subsampling on
+    the side stream or in line, the split modes return the same tokens and the same encoder frames, bit for bit."""
+    from ctc_vr_amd.online_rnnt_model import StreamingBatch
+    x = torch.from_numpy(T.synth_fbank(6, 1000, seed=77)).cuda().contiguous()
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        sb = StreamingBatch(np_state_dict(0), 6, max_chunk_frames=32, max_cache_frames=256, max_enc_frames=256, numerics=mode)
+        toks = sb.decode_script(x, 16, pipelined=True)
+        return toks, np.array(sb.engine.enc_frames(s), copy=True)
+
+    base_t, base_e = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got_t, got_e = run()                                           # a new context reads the knobs at rnnt_create
+    assert got_t == base_t, env
+    assert np.array_equal(got_e, base_e), env
+
+
 def test_long_utterance_pipelined_equals_per_chunk(np_state_dict, numerics):
     """30 s utterances (562 cached keys per layer at the end, 186 chunks: many wavefront stages, streaming attention over
     several 64-key rounds, tail-merged last chunk): whole-utterance call == per-chunk API, for two chunk sizes."""
